@@ -1,0 +1,219 @@
+"""cuda-vp9_amd — host-side Python mirror of the libvp9hip.so C-ABI (include/vp9hip.h).
+
+This package is plumbing for tests, the benchmark and the multi-GPU batch harness: it loads
+the in-tree HIP library with ctypes, mirrors the C structs as numpy dtypes and wraps the
+entry points.  It contains no arithmetic and no CPU fallback: if libvp9hip.so is missing or
+no HIP device is usable, calls raise.
+
+The directory name carries a hyphen (the project's name); import it through
+``__graft_entry__.load_pkg()`` or ``tests/vp9ref.load_hip()``, which register it as
+``cuda_vp9_amd``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvp9hip.so")
+
+_lib = None
+
+
+class Vp9HipError(RuntimeError):
+    pass
+
+
+# ---- struct mirrors (include/vp9hip.h) ------------------------------------------------------
+class Frame(ctypes.Structure):
+    _fields_ = [("plane", ctypes.c_void_p * 3), ("stride", ctypes.c_int32 * 3),
+                ("width", ctypes.c_int32 * 3), ("height", ctypes.c_int32 * 3),
+                ("awidth", ctypes.c_int32 * 3), ("aheight", ctypes.c_int32 * 3),
+                ("bit_depth", ctypes.c_int32), ("hbd", ctypes.c_int32)]
+
+
+TXB_DTYPE = np.dtype([("coeff_off", "<u4"), ("x", "<u2"), ("y", "<u2"), ("plane", "u1"),
+                      ("tx_size", "u1"), ("tx_type", "u1"), ("reserved", "u1"), ("eob", "<u2"),
+                      ("reserved2", "<u2")])
+INTER_DTYPE = np.dtype([("dst_x", "<i2"), ("dst_y", "<i2"), ("w", "u1"), ("h", "u1"),
+                        ("plane", "u1"), ("flags", "u1"), ("pos_x", "<i4", (2,)),
+                        ("pos_y", "<i4", (2,)), ("ref", "u1", (2,)), ("step_x", "u1", (2,)),
+                        ("step_y", "u1", (2,)), ("reserved", "u1", (2,))])
+INTRA_DTYPE = np.dtype([("coeff_off", "<u4"), ("x", "<u2"), ("y", "<u2"), ("plane", "u1"),
+                        ("tx_size", "u1"), ("tx_type", "u1"), ("mode", "u1"), ("eob", "<u2"),
+                        ("flags", "u1"), ("reserved", "u1")])
+LFM_DTYPE = np.dtype([("left_y", "<u8", (4,)), ("above_y", "<u8", (4,)), ("int_4x4_y", "<u8"),
+                      ("left_uv", "<u2", (4,)), ("above_uv", "<u2", (4,)), ("int_4x4_uv", "<u2"),
+                      ("lfl_y", "u1", (64,)), ("reserved", "u1", (6,))])
+assert TXB_DTYPE.itemsize == 16 and INTER_DTYPE.itemsize == 32
+assert INTRA_DTYPE.itemsize == 16 and LFM_DTYPE.itemsize == 160
+
+
+class LfThresh(ctypes.Structure):
+    _fields_ = [("mblim", ctypes.c_uint8 * 64), ("lim", ctypes.c_uint8 * 64),
+                ("hev_thr", ctypes.c_uint8 * 64)]
+
+
+def lib():
+    """The C-ABI library.  Raises if it has not been built — there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Vp9HipError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp = ctypes.c_void_p
+        L.vp9hip_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.vp9hip_destroy.argtypes = [vp]
+        L.vp9hip_destroy.restype = None
+        L.vp9hip_last_error.argtypes = [vp]
+        L.vp9hip_last_error.restype = ctypes.c_char_p
+        L.vp9hip_stream.argtypes = [vp]
+        L.vp9hip_stream.restype = vp
+        L.vp9hip_sync.argtypes = [vp]
+        L.vp9hip_malloc.argtypes = [vp, ctypes.c_size_t]
+        L.vp9hip_malloc.restype = vp
+        L.vp9hip_free.argtypes = [vp, vp]
+        L.vp9hip_free.restype = None
+        L.vp9hip_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
+        L.vp9hip_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_size_t]
+        L.vp9hip_memset.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t]
+        _lib = L
+    return _lib
+
+
+class DevBuf:
+    """A device allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        self.ptr = lib().vp9hip_malloc(ctx.handle, self.nbytes)
+        if not self.ptr:
+            raise Vp9HipError(ctx.error())
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx.check(lib().vp9hip_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx.check(lib().vp9hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().vp9hip_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class DevFrame:
+    """Three planes in HBM + the Frame descriptor the kernels take."""
+
+    def __init__(self, ctx, width, height, bit_depth=8, hbd=None, ss_x=1, ss_y=1, stride_align=64):
+        self.ctx = ctx
+        self.bit_depth = bit_depth
+        self.hbd = (bit_depth > 8) if hbd is None else bool(hbd)
+        self.dtype = np.uint16 if self.hbd else np.uint8
+        aw, ah = (width + 7) & ~7, (height + 7) & ~7
+        self.dims = []
+        for p in range(3):
+            sx, sy = (ss_x, ss_y) if p else (0, 0)
+            w, h = (width + sx) >> sx, (height + sy) >> sy
+            paw, pah = aw >> sx, ah >> sy
+            stride = (paw + stride_align - 1) // stride_align * stride_align
+            self.dims.append((w, h, paw, pah, stride))
+        self.bufs = [DevBuf(ctx, d[4] * d[3] * np.dtype(self.dtype).itemsize) for d in self.dims]
+        self.desc = Frame()
+        for p, d in enumerate(self.dims):
+            self.desc.plane[p] = self.bufs[p].ptr
+            self.desc.width[p], self.desc.height[p] = d[0], d[1]
+            self.desc.awidth[p], self.desc.aheight[p], self.desc.stride[p] = d[2], d[3], d[4]
+        self.desc.bit_depth = bit_depth
+        self.desc.hbd = int(self.hbd)
+
+    def upload(self, planes):
+        """planes: three 2-D arrays of the aligned plane size (aheight x awidth)."""
+        for p, (arr, d) in enumerate(zip(planes, self.dims)):
+            full = np.zeros((d[3], d[4]), self.dtype)
+            full[:, :d[2]] = arr[:d[3], :d[2]]
+            self.bufs[p].upload(full)
+
+    def download(self):
+        out = []
+        for p, d in enumerate(self.dims):
+            full = self.bufs[p].download(self.dtype, (d[3], d[4]))
+            out.append(full[:, :d[2]].copy())
+        return out
+
+    def free(self):
+        for b in self.bufs:
+            b.free()
+
+
+class Context:
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        rc = lib().vp9hip_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise Vp9HipError(f"vp9hip_create({device}) failed ({rc}): "
+                              f"{lib().vp9hip_last_error(None).decode()}")
+        self.handle = h
+
+    def error(self):
+        return lib().vp9hip_last_error(self.handle).decode()
+
+    def check(self, rc):
+        if rc != 0:
+            raise Vp9HipError(f"vp9hip call failed ({rc}): {self.error()}")
+
+    def sync(self):
+        self.check(lib().vp9hip_sync(self.handle))
+
+    def stream(self):
+        return lib().vp9hip_stream(self.handle)
+
+    def alloc(self, arr_or_bytes):
+        if isinstance(arr_or_bytes, (int, np.integer)):
+            return DevBuf(self, arr_or_bytes)
+        arr = np.ascontiguousarray(arr_or_bytes)
+        return DevBuf(self, max(arr.nbytes, 16)).upload(arr)
+
+    # ---- batched entry points --------------------------------------------------------------
+    def idct_add_batch(self, d_blocks, size_count, d_coeffs, frame):
+        sc = (ctypes.c_int32 * 4)(*[int(v) for v in size_count])
+        self.check(lib().vp9hip_idct_add_batch(self.handle, ctypes.c_void_p(d_blocks.ptr), sc,
+                                               ctypes.c_void_p(d_coeffs.ptr), ctypes.byref(frame.desc)))
+
+    def inter_pred_batch(self, d_tasks, n_tasks, refs, dst):
+        arr = (Frame * len(refs))(*[r.desc for r in refs])
+        self.check(lib().vp9hip_inter_pred_batch(self.handle, ctypes.c_void_p(d_tasks.ptr), int(n_tasks),
+                                                 arr, len(refs), ctypes.byref(dst.desc)))
+
+    def intra_pred_waves(self, d_tasks, wave_start, d_coeffs, frame):
+        ws = np.ascontiguousarray(wave_start, np.int32)
+        self.check(lib().vp9hip_intra_pred_waves(
+            self.handle, ctypes.c_void_p(d_tasks.ptr), ws.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+            len(ws) - 1, ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
+            ctypes.byref(frame.desc)))
+
+    def loop_filter_frame(self, d_lfm, sb_rows, sb_cols, thresh, frame, planes=3):
+        self.check(lib().vp9hip_loop_filter_frame(self.handle, ctypes.c_void_p(d_lfm.ptr), int(sb_rows),
+                                                  int(sb_cols), ctypes.byref(thresh), ctypes.byref(frame.desc),
+                                                  int(planes)))
+
+    def close(self):
+        if self.handle:
+            lib().vp9hip_destroy(self.handle)
+            self.handle = None
+
+
+def sort_txb_by_size(blocks):
+    """Group transform-block records by tx_size as vp9hip_idct_add_batch requires."""
+    order = np.argsort(blocks["tx_size"], kind="stable")
+    out = blocks[order]
+    counts = [int((out["tx_size"] == s).sum()) for s in range(4)]
+    return out, counts

@@ -1,0 +1,106 @@
+// vp9hip_api.hip — context, memory plumbing (C-style host code, C-ABI exports).
+#include "vp9hip_internal.h"
+
+#include <stdlib.h>
+
+static char g_err[512] = "no context";
+
+extern "C" int vp9hip_abi_version(void) { return VP9HIP_ABI_VERSION; }
+
+extern "C" int vp9hip_create(int device, vp9hip_ctx **out) {
+  if (!out) return VP9HIP_EINVAL;
+  *out = NULL;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    snprintf(g_err, sizeof(g_err), "no HIP device available (%s)", hipGetErrorString(e));
+    return VP9HIP_EDEVICE;
+  }
+  if (device < 0 || device >= n) {
+    snprintf(g_err, sizeof(g_err), "device %d out of range (0..%d)", device, n - 1);
+    return VP9HIP_EINVAL;
+  }
+  vp9hip_ctx *ctx = (vp9hip_ctx *)calloc(1, sizeof(*ctx));
+  if (!ctx) return VP9HIP_ENOMEM;
+  ctx->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "context creation failed: %s", hipGetErrorString(e));
+    free(ctx);
+    return VP9HIP_EDEVICE;
+  }
+  hipDeviceProp_t prop;
+  ctx->cu_count = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
+  ctx->err[0] = 0;
+  *out = ctx;
+  return VP9HIP_OK;
+}
+
+extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  (void)hipStreamDestroy(ctx->stream);
+  free(ctx);
+}
+
+extern "C" const char *vp9hip_last_error(const vp9hip_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+extern "C" void *vp9hip_stream(vp9hip_ctx *ctx) { return ctx ? (void *)ctx->stream : NULL; }
+
+extern "C" int vp9hip_sync(vp9hip_ctx *ctx) {
+  if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return VP9HIP_OK;
+}
+
+extern "C" void *vp9hip_malloc(vp9hip_ctx *ctx, size_t bytes) {
+  if (!ctx) return NULL;
+  void *p = NULL;
+  (void)hipSetDevice(ctx->device);
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    snprintf(ctx->err, sizeof(ctx->err), "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return NULL;
+  }
+  return p;
+}
+
+extern "C" void vp9hip_free(vp9hip_ctx *ctx, void *dptr) {
+  if (!ctx || !dptr) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dptr);
+}
+
+extern "C" int vp9hip_memcpy_h2d(vp9hip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  VP9HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_memcpy_d2h(vp9hip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  VP9HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_memset(vp9hip_ctx *ctx, void *dst, int value, size_t bytes) {
+  if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+  return VP9HIP_OK;
+}
+
+int vp9hip_ensure_scratch(vp9hip_ctx *ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return VP9HIP_OK;
+  VP9HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  ctx->scratch = NULL;
+  ctx->scratch_bytes = 0;
+  size_t want = bytes + (bytes >> 2);
+  VP9HIP_CHECK(ctx, hipMalloc(&ctx->scratch, want));
+  ctx->scratch_bytes = want;
+  return VP9HIP_OK;
+}
