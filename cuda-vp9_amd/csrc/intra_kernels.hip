@@ -1,0 +1,322 @@
+// intra_kernels.hip — intra prediction (+ fused residual add), dependency-wave ordered
+// (SURVEY §8 a8–a10).
+//
+// One launch per dependency wave; inside a launch every transform block is independent.
+// A block gets a 32-lane slot (8 slots per 256-thread workgroup): the lanes assemble the edge
+// (vp9_reconintra.c:262-402 build_intra_predictors: 127/129-style fill, frame-edge replication,
+// above-right only for 4x4-with-have_right) into LDS as one array E[-bs..2bs] with
+// E[0] = above-left, E[k] = above[k-1], E[-k] = left[k-1]; lane c then evaluates the closed
+// form of the predictor for column c (vpx_dsp/intrapred.c, derivations in DESIGN.md §intra),
+// runs the inverse transform of the block's coefficients exactly like txfm_kernels.hip and
+// stores clip(pred + residual).
+//
+// Algorithmic bytes per block: bs*bs*bps written + (3*bs+1)*bps edge reads + 16 (+ bs*bs*4
+// coefficients when coded).
+#include "txfm_device.h"
+#include "vp9hip_internal.h"
+
+namespace {
+
+constexpr int SLOT = 32;
+constexpr int SLOTS = 8;
+constexpr int EOFF = 32;          // index of E[0]
+constexpr int ESIZE = 32 + 1 + 64;
+constexpr int TPITCH = 33;
+
+#define AVG2(a, b) (((a) + (b) + 1) >> 1)
+#define AVG3(a, b, c) (((a) + 2 * (b) + (c) + 2) >> 2)
+
+__device__ __forceinline__ int clip_to(int v, int maxv) { return v < 0 ? 0 : (v > maxv ? maxv : v); }
+
+// P(r,c) for one column c, rows 0..BS-1, from the LDS edge array.
+template <int BS>
+__device__ __forceinline__ void predict_column(int mode, int c, const int *E, bool have_top, bool have_left,
+                                               int bd, int *p) {
+  const int maxv = (1 << bd) - 1;
+  const int *A = E + 1;  // A[i] = above[i], A[-1] = above-left
+  switch (mode) {
+    case 0: {  // DC family: dc_pred[left][up] (vp9_reconintra.c:86-89)
+      int sum = 0, cnt = 0;
+      if (have_top) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) sum += A[i];
+        cnt += BS;
+      }
+      if (have_left) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) sum += E[-1 - i];
+        cnt += BS;
+      }
+      const int dc = cnt ? (sum + (cnt >> 1)) / cnt : (128 << (bd - 8));
+#pragma unroll
+      for (int r = 0; r < BS; ++r) p[r] = dc;
+      break;
+    }
+    case 1:  // V
+#pragma unroll
+      for (int r = 0; r < BS; ++r) p[r] = A[c];
+      break;
+    case 2:  // H
+#pragma unroll
+      for (int r = 0; r < BS; ++r) p[r] = E[-1 - r];
+      break;
+    case 9: {  // TM
+      const int tl = A[-1], a = A[c];
+#pragma unroll
+      for (int r = 0; r < BS; ++r) p[r] = clip_to(E[-1 - r] + a - tl, maxv);
+      break;
+    }
+    case 3:  // D45 (intrapred.c:65-81 generic, :354-373 4x4)
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        const int i = r + c;
+        if (BS == 4)
+          p[r] = (i == 6) ? A[7] : AVG3(A[i], A[i + 1], A[i + 2]);
+        else
+          p[r] = (i < BS - 1) ? AVG3(A[i], A[i + 1], A[i + 2]) : A[BS - 1];
+      }
+      break;
+    case 8:  // D63 (:47-63 generic, :308-329 4x4)
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        const int k = r >> 1, i = c + k;
+        if (BS != 4 && r >= 2 && c >= BS - 1 - k)
+          p[r] = A[BS - 1];
+        else
+          p[r] = (r & 1) ? AVG3(A[i], A[i + 1], A[i + 2]) : AVG2(A[i], A[i + 1]);
+      }
+      break;
+    case 7:  // D207 (:21-45): walks down the left edge, L[j] = E[-1-j]
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        const int i = r + (c >> 1);
+        if (i >= BS - 1)
+          p[r] = E[-BS];
+        else if (!(c & 1))
+          p[r] = AVG2(E[-1 - i], E[-2 - i]);
+        else
+          p[r] = AVG3(E[-1 - i], E[-2 - i], E[-1 - (i + 2 < BS ? i + 2 : BS - 1)]);
+      }
+      break;
+    case 4:  // D135 (:109-139): constant along d = c - r, AVG3(E[d-1],E[d],E[d+1]) around E[d]
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        const int d = c - r;
+        p[r] = AVG3(E[d - 1], E[d], E[d + 1]);
+      }
+      break;
+    case 5:  // D117 (:83-107): P(r,c) = P(r-2,c-1)
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        const int k = (r >> 1) < c ? (r >> 1) : c;
+        const int rr = r - 2 * k, cc = c - k;
+        if (rr == 0)
+          p[r] = AVG2(E[cc], E[cc + 1]);
+        else if (rr == 1)
+          p[r] = AVG3(E[cc - 1], E[cc], E[cc + 1]);
+        else
+          p[r] = AVG3(E[2 - rr], E[1 - rr], E[-rr]);
+      }
+      break;
+    case 6:  // D153 (:141-165): P(r,c) = P(r-1,c-2)
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        const int k = r < (c >> 1) ? r : (c >> 1);
+        const int rr = r - k, cc = c - 2 * k;
+        if (cc == 0)
+          p[r] = AVG2(E[-rr], E[-rr - 1]);
+        else if (cc == 1)
+          p[r] = AVG3(E[1 - rr], E[-rr], E[-rr - 1]);
+        else
+          p[r] = AVG3(E[cc - 2], E[cc - 1], E[cc]);
+      }
+      break;
+    default:
+#pragma unroll
+      for (int r = 0; r < BS; ++r) p[r] = 0;
+  }
+}
+
+template <int N, bool HBD>
+__device__ __forceinline__ void row_pass(int *tile, int t, int tx_type, bool lossless) {
+  int v[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = tile[t * TPITCH + k];
+  if (lossless) {
+    if constexpr (N == 4) txfm::iwht4(v, true);
+  } else if (N < 32 && (tx_type & 2)) {
+    if constexpr (N < 32) txfm::iadst1d<N, HBD>(v);
+  } else {
+    txfm::idct1d<N, HBD>(v);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) tile[t * TPITCH + k] = v[k];
+}
+
+template <int N, bool HBD>
+__device__ __forceinline__ void col_pass(const int *tile, int t, int tx_type, bool lossless, int *v) {
+  constexpr int shift = N == 4 ? 4 : (N == 8 ? 5 : 6);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = tile[k * TPITCH + t];
+  if (lossless) {
+    if constexpr (N == 4) txfm::iwht4(v, false);
+    return;
+  }
+  if (N < 32 && (tx_type & 1)) {
+    if constexpr (N < 32) txfm::iadst1d<N, HBD>(v);
+  } else {
+    txfm::idct1d<N, HBD>(v);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = txfm::add32(v[k], 1 << (shift - 1)) >> shift;
+}
+
+template <int N, typename Pix, bool HBD>
+__device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t, const int *E, const int *tile,
+                                             bool coded, int dc_coeff, int dc_kind, const FrameDev &f) {
+  if (t >= N) return;
+  int p[N];
+  predict_column<N>(tk.mode, t, E, tk.flags & 1, (tk.flags >> 1) & 1, f.bit_depth, p);
+  if (coded) {
+    int v[N];
+    if (dc_kind == 1) {  // vpx_idctNxN_1_add_c
+      const int a1 = txfm::dc_only<N, HBD>(dc_coeff);
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = a1;
+    } else if (dc_kind == 2) {  // vpx_iwht4x4_1_add_c
+      txfm::i64 a1 = dc_coeff >> 2, e1 = a1 >> 1;
+      a1 -= e1;
+      const int ip = t == 0 ? (int)a1 : (int)e1;
+      const int e = ip >> 1;
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = e;
+      v[0] = ip - e;
+    } else {
+      col_pass<N, HBD>(tile, t, tk.tx_type & 3, tk.tx_type & 0x80, v);
+    }
+    const int maxv = (1 << f.bit_depth) - 1;
+#pragma unroll
+    for (int k = 0; k < N; ++k) p[k] = clip_to(txfm::add32(p[k], v[k]), maxv);
+  }
+  const int pl = tk.plane;
+  const int x = tk.x + t;
+  if (x >= f.awidth[pl]) return;
+  Pix *dst = (Pix *)f.plane[pl] + (size_t)tk.y * f.stride[pl] + x;
+  const int rows = min(N, f.aheight[pl] - (int)tk.y);
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (k < rows) dst[(size_t)k * f.stride[pl]] = (Pix)p[k];
+}
+
+template <typename Pix, bool HBD>
+__global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task *__restrict__ tasks, int first,
+                                                         int count, const int32_t *__restrict__ coeffs, FrameDev f) {
+  __shared__ int edge[SLOTS][ESIZE];
+  __shared__ int tiles[SLOTS][32 * TPITCH];
+  const int slot = threadIdx.x / SLOT, t = threadIdx.x % SLOT;
+  const int ti = blockIdx.x * SLOTS + slot;
+  const bool active = ti < count;
+  vp9hip_intra_task tk;
+  memset(&tk, 0, sizeof(tk));
+  if (active) tk = tasks[first + ti];
+  const int bs = 4 << tk.tx_size;
+  const int pl = tk.plane;
+  const bool lossless = tk.tx_type & 0x80;
+  // coded: residual present; eob<=1 blocks take the DC-only forms (vp9_idct.c:119-204)
+  const bool coded = active && coeffs != nullptr && tk.eob > 0;
+  int *E = edge[slot] + EOFF;
+  int *tile = tiles[slot];
+  int dc_kind = 0, dc_coeff = 0;
+
+  if (active) {
+    const Pix *plane = (const Pix *)f.plane[pl];
+    const int stride = f.stride[pl];
+    const int fw = f.awidth[pl], fh = f.aheight[pl];
+    const int base = 128 << (f.bit_depth - 8);
+    const bool have_top = tk.flags & 1, have_left = (tk.flags >> 1) & 1, have_right = (tk.flags >> 2) & 1;
+    const int x = tk.x, y = tk.y;
+    // above: entries 0..2bs-1 (+ above-left); AR rule of vp9_reconintra.c:349-393 — entries
+    // below bs are identical to the above-only rule (:322-347)
+    {
+      int take;
+      const bool ext = (bs == 4 && have_right);
+      if (x + 2 * bs <= fw)
+        take = ext ? 2 * bs : bs;
+      else if (x + bs <= fw)
+        take = ext ? fw - x : bs;
+      else
+        take = fw - x;
+      for (int i = t; i < 2 * bs; i += SLOT) {
+        int v;
+        if (have_top)
+          v = plane[(size_t)(y - 1) * stride + x + (i < take ? i : take - 1)];
+        else
+          v = base - 1;
+        E[1 + i] = v;
+      }
+      if (t == 0) E[0] = have_top ? (have_left ? (int)plane[(size_t)(y - 1) * stride + x - 1] : base + 1) : base - 1;
+    }
+    {
+      const int valid = (y + bs <= fh) ? bs : fh - y;
+      for (int i = t; i < bs; i += SLOT) {
+        int v;
+        if (have_left)
+          v = plane[(size_t)(y + (i < valid ? i : valid - 1)) * stride + x - 1];
+        else
+          v = base + 1;
+        E[-1 - i] = v;
+      }
+    }
+    if (coded) {
+      const int32_t *src = coeffs + tk.coeff_off;
+      if (!lossless && ((tk.tx_type & 3) == 0 || bs == 32) && (bs == 4 ? tk.eob <= 1 : tk.eob == 1)) dc_kind = 1;
+      if (lossless && tk.eob <= 1) dc_kind = 2;
+      if (dc_kind)
+        dc_coeff = src[0];  // only the DC term is defined (and read) at eob <= 1
+      else if (t < bs)
+        for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = src[i * bs + t];
+    }
+  }
+  __syncthreads();
+  if (coded && !dc_kind && t < bs) {
+    const int tt = tk.tx_type & 3;
+    switch (tk.tx_size) {
+      case 0: row_pass<4, HBD>(tile, t, tt, lossless); break;
+      case 1: row_pass<8, HBD>(tile, t, tt, false); break;
+      case 2: row_pass<16, HBD>(tile, t, tt, false); break;
+      default: row_pass<32, HBD>(tile, t, 0, false); break;
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  switch (tk.tx_size) {
+    case 0: finish_block<4, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
+    case 1: finish_block<8, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
+    case 2: finish_block<16, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
+    default: finish_block<32, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
+  }
+}
+
+}  // namespace
+
+extern "C" int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks, const int32_t *wave_start,
+                                       int n_waves, const int32_t *d_coeffs, const vp9hip_frame *frame) {
+  if (!ctx) return VP9HIP_EINVAL;
+  if (!d_tasks || !wave_start || n_waves < 0 || !frame_ok(frame))
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_waves: bad argument");
+  const FrameDev f = to_dev(frame);
+  for (int w = 0; w < n_waves; ++w) {
+    const int first = wave_start[w], count = wave_start[w + 1] - first;
+    if (count < 0) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_waves: wave_start not monotonic");
+    if (count == 0) continue;
+    const int grid = (count + SLOTS - 1) / SLOTS;
+    if (frame->hbd)
+      hipLaunchKernelGGL((intra_wave_kernel<uint16_t, true>), dim3(grid), dim3(256), 0, ctx->stream, d_tasks, first,
+                         count, d_coeffs, f);
+    else
+      hipLaunchKernelGGL((intra_wave_kernel<uint8_t, false>), dim3(grid), dim3(256), 0, ctx->stream, d_tasks, first,
+                         count, d_coeffs, f);
+  }
+  VP9HIP_CHECK(ctx, hipGetLastError());
+  return VP9HIP_OK;
+}

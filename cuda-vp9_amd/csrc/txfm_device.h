@@ -561,5 +561,21 @@ __device__ __forceinline__ void iwht4(int *v, bool first) {
   v[3] = (int)d;
 }
 
+// DC-only value: vpx_idctNxN_1_add_c (inv_txfm.c:178-194 ...), highbd (:1476-1494 ...)
+template <int N, bool HBD>
+__device__ __forceinline__ int dc_only(int dc) {
+  constexpr int shift = N == 4 ? 4 : (N == 8 ? 5 : 6);
+  int out;
+  if constexpr (HBD) {
+    out = rs14_i64((i64)dc * kCos[16]);
+    out = rs14_i64((i64)out * kCos[16]);
+  } else {
+    out = rs14_i32((int)(short)dc * kCos[16]);
+    out = rs14_i32(mul32(out, kCos[16]));
+  }
+  return add32(out, 1 << (shift - 1)) >> shift;
+}
+
+
 }  // namespace txfm
 #endif

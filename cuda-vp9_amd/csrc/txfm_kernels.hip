@@ -16,21 +16,6 @@ __device__ __forceinline__ int clip_pix(int v, int maxv) {
   return v < 0 ? 0 : (v > maxv ? maxv : v);
 }
 
-// DC-only value: vpx_idctNxN_1_add_c (inv_txfm.c:178-194 ...), highbd (:1476-1494 ...)
-template <int N, bool HBD>
-__device__ __forceinline__ int dc_only(int dc) {
-  constexpr int shift = N == 4 ? 4 : (N == 8 ? 5 : 6);
-  int out;
-  if constexpr (HBD) {
-    out = txfm::rs14_i64((txfm::i64)dc * txfm::kCos[16]);
-    out = txfm::rs14_i64((txfm::i64)out * txfm::kCos[16]);
-  } else {
-    out = txfm::rs14_i32((int)(short)dc * txfm::kCos[16]);
-    out = txfm::rs14_i32(txfm::mul32(out, txfm::kCos[16]));
-  }
-  return txfm::add32(out, 1 << (shift - 1)) >> shift;
-}
-
 template <int N, typename Pix, bool HBD>
 __global__ __launch_bounds__(256) void idct_add_kernel(const vp9hip_txb *__restrict__ blocks, int n_blocks,
                                                        const int32_t *__restrict__ coeffs, FrameDev f) {
@@ -77,7 +62,7 @@ __global__ __launch_bounds__(256) void idct_add_kernel(const vp9hip_txb *__restr
 
   constexpr int shift = N == 4 ? 4 : (N == 8 ? 5 : 6);
   if (dc_path) {
-    const int a1 = dc_only<N, HBD>(src[0]);
+    const int a1 = txfm::dc_only<N, HBD>(src[0]);
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = a1;
   } else if (wht_dc) {  // vpx_iwht4x4_1_add_c (inv_txfm.c:71-94)

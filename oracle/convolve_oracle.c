@@ -159,3 +159,69 @@ void vp9o_highbd_convolve(int mode, int scaled, const uint16_t *src, ptrdiff_t s
   convolve_generic(mode, src, src_stride, dst, dst_stride, kernel, x0_q4, x_step_q4, y0_q4,
                    y_step_q4, w, h, (1 << bd) - 1);
 }
+
+/* ---- block-level inter predictor with decoder border emulation --------------------------
+ * Restates dec_build_inter_predictors + build_mc_border / high_build_mc_border +
+ * extend_and_predict (vp9/decoder/vp9_decodeframe.c:432-690) for one block and one
+ * reference: the (w+7)x(h+7) window is fetched with coordinates clamped to the reference
+ * plane's crop size [0,fw-1]x[0,fh-1] (that is what the emulated border holds; blocks fully
+ * inside read the same pixels directly), then handed to the predictor the scale-factor table
+ * selects (vp9/common/vp9_scale.c:79-170): copy / horiz / vert / 2-D by which phase is
+ * non-zero, the vpx_scaled_* forms when a step differs from 16.
+ * pos_q4 = 16*integer position + phase of the block's first sample. */
+static void inter_block(const uint8_t *ref8, const uint16_t *ref16, int rstride, int fw, int fh,
+                        int px_q4, int py_q4, int xs, int ys, int filter, int w, int h,
+                        uint8_t *dst8, uint16_t *dst16, int dstride, int avg, int bd) {
+  static __thread uint16_t win[(64 * 2 + 16) * (64 * 2 + 16)];
+  const int WS = 64 * 2 + 16;
+  const int x0 = px_q4 >> 4, y0 = py_q4 >> 4, subx = px_q4 & 15, suby = py_q4 & 15;
+  const int ww = (((w - 1) * xs + subx) >> 4) + 8, wh = (((h - 1) * ys + suby) >> 4) + 8;
+  for (int r = 0; r < wh; ++r)
+    for (int c = 0; c < ww; ++c) {
+      int sx = x0 - 3 + c, sy = y0 - 3 + r;
+      sx = sx < 0 ? 0 : sx > fw - 1 ? fw - 1 : sx;
+      sy = sy < 0 ? 0 : sy > fh - 1 ? fh - 1 : sy;
+      win[r * WS + c] = ref16 ? ref16[sy * rstride + sx] : ref8[sy * rstride + sx];
+    }
+  /* sf->predict[subpel_x != 0][subpel_y != 0][avg], vp9_scale.c:79-130 */
+  int do_h, do_v;
+  if (xs == 16 && ys == 16) {
+    do_h = subx != 0;
+    do_v = suby != 0;
+  } else if (xs == 16) { /* y scaled: always vertical; 2-D when x has a phase */
+    do_h = subx != 0;
+    do_v = 1;
+  } else if (ys == 16) {
+    do_h = 1;
+    do_v = suby != 0;
+  } else {
+    do_h = do_v = 1;
+  }
+  const int mode = do_h | (do_v << 1) | (avg ? 4 : 0);
+  uint16_t d16[64 * 64];
+  for (int r = 0; r < h; ++r)
+    for (int c = 0; c < w; ++c) d16[r * 64 + c] = dst16 ? dst16[r * dstride + c] : dst8[r * dstride + c];
+  convolve_generic(mode, win + 3 * WS + 3, WS, d16, 64, kBank[filter], subx, xs, suby, ys, w, h,
+                   (1 << bd) - 1);
+  for (int r = 0; r < h; ++r)
+    for (int c = 0; c < w; ++c) {
+      if (dst16)
+        dst16[r * dstride + c] = d16[r * 64 + c];
+      else
+        dst8[r * dstride + c] = (uint8_t)d16[r * 64 + c];
+    }
+}
+
+void vp9o_inter_predict_block(const uint8_t *ref, int ref_stride, int fw, int fh, int px_q4,
+                              int py_q4, int xs, int ys, int filter, int w, int h, uint8_t *dst,
+                              int dst_stride, int avg) {
+  inter_block(ref, NULL, ref_stride, fw, fh, px_q4, py_q4, xs, ys, filter, w, h, dst, NULL,
+              dst_stride, avg, 8);
+}
+
+void vp9o_highbd_inter_predict_block(const uint16_t *ref, int ref_stride, int fw, int fh,
+                                     int px_q4, int py_q4, int xs, int ys, int filter, int w,
+                                     int h, uint16_t *dst, int dst_stride, int avg, int bd) {
+  inter_block(NULL, ref, ref_stride, fw, fh, px_q4, py_q4, xs, ys, filter, w, h, NULL, dst,
+              dst_stride, avg, bd);
+}

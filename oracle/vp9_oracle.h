@@ -70,6 +70,16 @@ void vp9o_highbd_convolve(int mode, int scaled, const uint16_t *src,
                           const int16_t (*kernel)[8], int x0_q4, int x_step_q4,
                           int y0_q4, int y_step_q4, int w, int h, int bd);
 
+/* Block-level inter predictor with the decoder's border emulation:
+ * dec_build_inter_predictors, vp9/decoder/vp9_decodeframe.c:563-690.  ref points at plane
+ * sample (0,0); fw/fh = crop size of the reference plane. */
+void vp9o_inter_predict_block(const uint8_t *ref, int ref_stride, int fw, int fh, int px_q4,
+                              int py_q4, int xs, int ys, int filter, int w, int h, uint8_t *dst,
+                              int dst_stride, int avg);
+void vp9o_highbd_inter_predict_block(const uint16_t *ref, int ref_stride, int fw, int fh,
+                                     int px_q4, int py_q4, int xs, int ys, int filter, int w,
+                                     int h, uint16_t *dst, int dst_stride, int avg, int bd);
+
 /* ---- intra predictors --------------------------------- */
 
 /* mode numbering as PREDICTION_MODE (vp9/common/vp9_blockd.h): 0 DC, 1 V, 2 H,
@@ -89,16 +99,13 @@ void vp9o_highbd_intra_predictor(int mode, int bs, uint16_t *dst, ptrdiff_t stri
 /* Edge builder + dispatch: build_intra_predictors (vp9_reconintra.c:262-402),
  * high variant (:113-259).  ref/dst point at the block's top-left pixel in the
  * frame being reconstructed.  frame_width/height are the plane's ALIGNED
- * dimensions (y_width / uv_width), x,y the block position in plane pixels,
- * xr = pixels available to the right inside the frame computed as libvpx does
- * ((mb_to_right_edge>>(3+ss_x)) + (wpx - x - txwpx)), yd likewise. */
+ * dimensions (y_width / uv_width), x,y the block position in plane pixels. */
 typedef struct {
   int mode;        /* 0..9 */
   int bs;          /* 4,8,16,32 */
   int have_top, have_left, have_right;
   int x, y;        /* position of the tx block inside the plane (pixels) */
   int frame_width, frame_height; /* aligned plane dims (0 => no edge handling) */
-  int xr_valid;    /* 1 when mb_to_right_edge < 0 style clipping applies */
 } vp9o_intra_args;
 void vp9o_predict_intra(const vp9o_intra_args *a, const uint8_t *ref, int ref_stride,
                         uint8_t *dst, int dst_stride);
