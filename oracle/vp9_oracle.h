@@ -124,6 +124,22 @@ void vp9o_highbd_lpf(int vertical, int kind, int dual, uint16_t *s, int pitch,
                      const uint8_t *b0, const uint8_t *l0, const uint8_t *t0,
                      const uint8_t *b1, const uint8_t *l1, const uint8_t *t1, int bd);
 
+/* Loop-filter driver for a whole frame: loop_filter_rows +
+ * vp9_filter_block_plane_ss00/ss11 + filter_selectively_* (vp9_loopfilter.c:297-650,
+ * 1241-1469).  lfm has the layout of LOOP_FILTER_MASK (vp9_loopfilter.h:60-68). */
+typedef struct {
+  uint64_t left_y[4], above_y[4], int_4x4_y;
+  uint16_t left_uv[4], above_uv[4], int_4x4_uv;
+  uint8_t lfl_y[64];
+  uint8_t reserved[6];
+} vp9o_lfm;
+typedef struct {
+  uint8_t mblim[64], lim[64], hev_thr[64];
+} vp9o_lf_thresh;
+void vp9o_loop_filter_frame(const vp9o_lfm *lfm, int sb_rows, int sb_cols, const vp9o_lf_thresh *th,
+                            void *const planes[3], const int strides[3], int mi_rows, int bd, int hbd,
+                            int nplanes);
+
 #ifdef __cplusplus
 }
 #endif

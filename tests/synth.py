@@ -47,3 +47,76 @@ def intra_levels(tasks, plane_dims):
         m[cy:cy + n, cx:cx + n] = lv
         levels.append(lv)
     return np.array(levels, np.int32)
+
+
+def random_lfm(rng, sb_rows, sb_cols, mi_rows, mi_cols, lfm_dtype, p_edge=0.6):
+    """Random but libvpx-legal LOOP_FILTER_MASK records: one filter size per edge position,
+    bits outside the frame removed the way vp9_adjust_mask does
+    (vp9/common/vp9_loopfilter.c:766-860)."""
+    out = np.zeros(sb_rows * sb_cols, lfm_dtype)
+    for sr in range(sb_rows):
+        for sc in range(sb_cols):
+            m = out[sr * sb_cols + sc]
+            rows = min(8, mi_rows - sr * 8)
+            cols = min(8, mi_cols - sc * 8)
+            lv = rng.integers(1, 64, 64).astype(np.uint8)
+            if rng.random() < 0.3:
+                lv[:] = rng.integers(1, 64)
+            m["lfl_y"] = lv
+
+            def pick(nbits):
+                kinds = rng.integers(0, 3, nbits)
+                on = rng.random(nbits) < p_edge
+                masks = [0, 0, 0]
+                for b in range(nbits):
+                    if on[b]:
+                        masks[kinds[b]] |= 1 << b
+                return masks
+
+            ly, ay = pick(64), pick(64)
+            luv, auv = pick(16), pick(16)
+            inty = int(rng.integers(0, 1 << 63)) & int(rng.integers(0, 1 << 63))
+            intuv = int(rng.integers(0, 1 << 16))
+            my = sum(((1 << cols) - 1) << (8 * r) for r in range(rows))
+            crows, ccols = (rows + 1) >> 1, (cols + 1) >> 1
+            muv = sum(((1 << ccols) - 1) << (4 * r) for r in range(crows))
+            muv_int = sum(((1 << (cols >> 1)) - 1) << (4 * r) for r in range(crows))
+            for k in range(3):
+                ly[k] &= my
+                ay[k] &= my
+                luv[k] &= muv
+                auv[k] &= muv
+            inty &= my
+            intuv &= muv_int
+            if rows & 1:   # partial last chroma row: no 16-wide filter there
+                rowbits = 0xf << (4 * (crows - 1))
+                auv[1] |= auv[2] & rowbits
+                auv[2] &= ~rowbits
+                # 8-wide needs 4 rows below: fine; keep
+            if cols & 1:
+                colbits = 0x1111 << (ccols - 1)
+                luv[1] |= luv[2] & colbits
+                luv[2] &= ~colbits
+            if sc == 0:
+                for k in range(3):
+                    ly[k] &= 0xfefefefefefefefe
+                    luv[k] &= 0xeeee
+            for k in range(3):
+                m["left_y"][k], m["above_y"][k] = ly[k], ay[k]
+                m["left_uv"][k], m["above_uv"][k] = luv[k], auv[k]
+            m["int_4x4_y"], m["int_4x4_uv"] = inty, intuv
+    return out
+
+
+def lf_thresholds(sharpness=0):
+    """lfthr table: update_sharpness + vp9_loop_filter_init (vp9_loopfilter.c:212-250)."""
+    mblim, lim, hev = np.zeros(64, np.uint8), np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+    for lvl in range(64):
+        bil = lvl >> ((sharpness > 0) + (sharpness > 4))
+        if sharpness > 0 and bil > 9 - sharpness:
+            bil = 9 - sharpness
+        bil = max(bil, 1)
+        lim[lvl] = bil
+        mblim[lvl] = 2 * (lvl + 2) + bil
+        hev[lvl] = lvl >> 4
+    return mblim, lim, hev
