@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — VP9 block-reconstruction throughput on MI355X.
+
+A "step" is one pass of the hot path (inter prediction -> inverse transform + add -> wave-ordered
+intra prediction -> loop filter) over one synthetic 2560x1440 8-bit 4:2:0 frame whose packed work
+lists and reference frames are already resident in HBM.  BASELINE.json's configs[1]
+(Bravia.1440.ivf) cannot be used: the clip is not in the reference snapshot; the workload is the
+seeded synthetic stand-in S-1440 (cuda-vp9_amd/workload.py).  One independent stream per GPU
+(--gpus N, launched with torch.distributed.run): no data-path collective, RCCL only for the
+barrier and the end-of-batch stats reduce.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=2560)
+    ap.add_argument("--height", type=int, default=1440)
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=4, help="distinct resident frames cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-phase-timers", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    pkg = g.load_pkg()
+    import cuda_vp9_amd.pipeline as pipeline
+    import cuda_vp9_amd.workload as workload
+
+    ctx = pkg.Context(local_rank)
+    wls = [workload.make_frame_workload(args.width, args.height, seed=1440 + i, bd=args.bit_depth)
+           for i in range(args.frames)]
+    jobs = [pipeline.FrameJob(ctx, wl) for wl in wls]
+    ab = [pipeline.algorithmic_bytes(wl) for wl in wls]
+    PH = ("inter", "txb", "intra", "lf")
+    KN = {"inter": "convolve", "txb": "idct_add", "intra": "intra", "lf": "loop_filter"}
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i, slot_base=None):
+        job = jobs[i % len(jobs)]
+        if slot_base is None:
+            job.run()
+            return
+        for k, ph in enumerate(PH):
+            ctx.timer_begin(slot_base + k)
+            job.run(phases=(ph,))
+            ctx.timer_end(slot_base + k)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    timers = not args.no_phase_timers
+    max_timed = 1000  # timer slots: 4 per step (VP9HIP_TIMER_SLOTS = 4096)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, slot_base=4 * (i % max_timed) if timers else None)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # per-kernel-family GPU time, measured with HIP events on the launch stream in the timed loop
+    phase_ms = {ph: 0.0 for ph in PH}
+    n_timed = min(args.steps, max_timed) if timers else 0
+    first = args.steps - n_timed
+    for i in range(first, args.steps):
+        for k, ph in enumerate(PH):
+            phase_ms[ph] += ctx.timer_read(4 * (i % max_timed) + k)
+    phase_ms = {ph: (v / n_timed if n_timed else None) for ph, v in phase_ms.items()}
+
+    # correctness of what was timed: frame 0 against the oracle (rank 0 only; small CPU cost)
+    md5_match = None
+    cpu_baseline = None
+    if rank == 0:
+        import frame_check
+        oracle = frame_check.load_oracle()
+        got = jobs[0].download()
+        exp, _ = frame_check.oracle_frame(oracle, wls[0])
+        md5_match = frame_check.frame_md5(got, wls[0]) == frame_check.frame_md5(exp, wls[0])
+        if world == 1 and not args.no_cpu_baseline:
+            n, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_seconds or n < 2:
+                _, times = frame_check.oracle_frame(oracle, wls[n % len(wls)])
+                t_cpu += sum(times.values())
+                n += 1
+            cpu_baseline = {"value": round(n / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                            "sample": f"{n} synthetic {args.width}x{args.height} frames (same work lists as the GPU "
+                                      f"run) through oracle/ C restatement, single thread, {t_cpu:.1f} s"}
+
+    # stats reduce: total frames (sum) and slowest rank (max) — the only collective in the harness
+    frames_total, t_max = float(args.steps), elapsed
+    if dist is not None:
+        v = torch.tensor([float(args.steps), 0.0], device="cuda", dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        m = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        frames_total, t_max = float(v[0].item()), float(m[0].item())
+
+    if rank == 0:
+        kernels = {}
+        if n_timed:
+            for ph in PH:
+                byts = sum(a[KN[ph]] for a in ab) / len(ab)
+                ms = phase_ms[ph]
+                gbs = byts / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
+                kernels[KN[ph]] = {"ms_per_frame": round(ms, 5), "algorithmic_bytes": int(byts),
+                                   "GB/s": round(gbs, 1) if gbs else None,
+                                   "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5) if gbs else None}
+        roofline = None
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None}
+        out = {
+            "metric": "decoded frames/sec (block-reconstruction path: inter+idct+intra+loop filter), 1440p VP9 8-bit",
+            "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8" if args.bit_depth == 8 else "u16",
+            "data": "synthetic",
+            "config": {"workload": f"S-{args.height}: synthetic {args.width}x{args.height} {args.bit_depth}-bit 4:2:0 "
+                                   f"inter frame ({wls[0]['n_blocks']} blocks, {len(wls[0]['inter_tasks'])} inter tasks, "
+                                   f"{len(wls[0]['txb'])} coded inter tx blocks, {len(wls[0]['intra_sorted'])} intra tx "
+                                   f"blocks in {wls[0]['n_waves']} waves, {wls[0]['sb_rows']}x{wls[0]['sb_cols']} SBs), "
+                                   f"{args.frames} distinct frames resident in HBM, one stream per GPU",
+                       "parallelism": f"streams{world}"},
+            "md5_match_vs_oracle": md5_match,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,9 @@ def lib():
         L.vp9hip_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
         L.vp9hip_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_size_t]
         L.vp9hip_memset.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t]
+        L.vp9hip_timer_begin.argtypes = [vp, ctypes.c_int]
+        L.vp9hip_timer_end.argtypes = [vp, ctypes.c_int]
+        L.vp9hip_timer_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         _lib = L
     return _lib
 
@@ -172,6 +175,17 @@ class Context:
 
     def sync(self):
         self.check(lib().vp9hip_sync(self.handle))
+
+    def timer_begin(self, slot):
+        self.check(lib().vp9hip_timer_begin(self.handle, slot))
+
+    def timer_end(self, slot):
+        self.check(lib().vp9hip_timer_end(self.handle, slot))
+
+    def timer_read(self, slot):
+        ms = ctypes.c_float()
+        self.check(lib().vp9hip_timer_read(self.handle, slot, ctypes.byref(ms)))
+        return ms.value
 
     def stream(self):
         return lib().vp9hip_stream(self.handle)

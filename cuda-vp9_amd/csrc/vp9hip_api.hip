@@ -41,6 +41,14 @@ extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->ev_begin) {
+    for (int i = 0; i < VP9HIP_TIMER_SLOTS; ++i) {
+      if (ctx->ev_begin[i]) (void)hipEventDestroy(ctx->ev_begin[i]);
+      if (ctx->ev_end[i]) (void)hipEventDestroy(ctx->ev_end[i]);
+    }
+    free(ctx->ev_begin);
+    free(ctx->ev_end);
+  }
   (void)hipStreamDestroy(ctx->stream);
   free(ctx);
 }
@@ -102,5 +110,43 @@ int vp9hip_ensure_scratch(vp9hip_ctx *ctx, size_t bytes) {
   size_t want = bytes + (bytes >> 2);
   VP9HIP_CHECK(ctx, hipMalloc(&ctx->scratch, want));
   ctx->scratch_bytes = want;
+  return VP9HIP_OK;
+}
+
+static int timer_slot(vp9hip_ctx *ctx, int slot) {
+  if (!ctx) return VP9HIP_EINVAL;
+  if (slot < 0 || slot >= VP9HIP_TIMER_SLOTS) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "timer slot %d out of range", slot);
+  if (!ctx->ev_begin) {
+    ctx->ev_begin = (hipEvent_t *)calloc(VP9HIP_TIMER_SLOTS, sizeof(hipEvent_t));
+    ctx->ev_end = (hipEvent_t *)calloc(VP9HIP_TIMER_SLOTS, sizeof(hipEvent_t));
+    if (!ctx->ev_begin || !ctx->ev_end) VP9HIP_FAIL(ctx, VP9HIP_ENOMEM, "out of host memory");
+  }
+  if (!ctx->ev_begin[slot]) {
+    VP9HIP_CHECK(ctx, hipEventCreate(&ctx->ev_begin[slot]));
+    VP9HIP_CHECK(ctx, hipEventCreate(&ctx->ev_end[slot]));
+  }
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_timer_begin(vp9hip_ctx *ctx, int slot) {
+  int rc = timer_slot(ctx, slot);
+  if (rc) return rc;
+  VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_begin[slot], ctx->stream));
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_timer_end(vp9hip_ctx *ctx, int slot) {
+  int rc = timer_slot(ctx, slot);
+  if (rc) return rc;
+  VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_end[slot], ctx->stream));
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_timer_read(vp9hip_ctx *ctx, int slot, float *ms) {
+  int rc = timer_slot(ctx, slot);
+  if (rc) return rc;
+  if (!ms) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_end[slot]));
+  VP9HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev_begin[slot], ctx->ev_end[slot]));
   return VP9HIP_OK;
 }

@@ -55,6 +55,16 @@ int vp9hip_abi_version(void);
 void *vp9hip_stream(vp9hip_ctx *ctx);
 int vp9hip_sync(vp9hip_ctx *ctx);
 
+/* GPU timing on the context's stream (hipEvent pairs).  slot in [0, VP9HIP_TIMER_SLOTS):
+ * vp9hip_timer_begin/end record events around whatever the caller enqueues in between;
+ * vp9hip_timer_read waits for the end event and ACCUMULATES nothing — it returns the elapsed
+ * milliseconds of that one begin/end pair.  Replaces the reference's clock()/cudaEvent pairs
+ * reported through *gpu_copy / *gpu_run (vpx-master/inter_cuda_kernel.cu:1069-1101). */
+#define VP9HIP_TIMER_SLOTS 4096
+int vp9hip_timer_begin(vp9hip_ctx *ctx, int slot);
+int vp9hip_timer_end(vp9hip_ctx *ctx, int slot);
+int vp9hip_timer_read(vp9hip_ctx *ctx, int slot, float *ms);
+
 /* Device memory plumbing for callers that do not bring their own allocator. */
 void *vp9hip_malloc(vp9hip_ctx *ctx, size_t bytes);
 void vp9hip_free(vp9hip_ctx *ctx, void *dptr);

@@ -140,6 +140,19 @@ void vp9o_loop_filter_frame(const vp9o_lfm *lfm, int sb_rows, int sb_cols, const
                             void *const planes[3], const int strides[3], int mi_rows, int bd, int hbd,
                             int nplanes);
 
+/* ---- whole-frame sequential reconstruction from packed work lists ---------------------- */
+typedef struct {
+  void *plane[3];
+  int32_t stride[3];
+  int32_t width[3], height[3];
+  int32_t awidth[3], aheight[3];
+  int32_t bit_depth, hbd;
+} vp9o_frame; /* same layout as vp9hip_frame, host pointers */
+void vp9o_recon_inter_list(const void *tasks, int n, const vp9o_frame *refs, const vp9o_frame *dst);
+void vp9o_recon_txb_list(const void *blocks, int n, const int32_t *coeffs, const vp9o_frame *f);
+void vp9o_recon_intra_list(const void *tasks /* decode order */, int n, const int32_t *coeffs,
+                           const vp9o_frame *f);
+
 #ifdef __cplusplus
 }
 #endif
