@@ -26,91 +26,94 @@ struct LfThreshDev {
   uint8_t mblim[64], lim[64], hev_thr[64];
 };
 
-constexpr int TP = 76;  // LDS tile pitch in samples (19 dwords for 8-bit: odd, conflict-free column walks)
-
-__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
-__device__ __forceinline__ int sclamp(int t, int bd) {
-  const int lo = -(128 << (bd - 8)), hi = (128 << (bd - 8)) - 1;
-  return t < lo ? lo : (t > hi ? hi : t);
-}
-
-// Filter one line across one edge.  b points at q0; taps at b[k*step].  vpx_dsp/loopfilter.c:
-// filter_mask :33, flat_mask4 :49, flat_mask5 :62, hev_mask :72, filter4 :76, filter8 :162,
-// filter16 :235; highbd forms :359-447 (thresholds << (bd-8)).
 template <typename Pix>
-__device__ __forceinline__ void filter_edge(Pix *b, int step, int kind, int blimit, int limit, int thresh, int bd) {
-  const int sh = bd - 8;
-  const int lim = limit << sh, blim = blimit << sh, one = 1 << sh, thr = thresh << sh;
-  const int p3 = b[-4 * step], p2 = b[-3 * step], p1 = b[-2 * step], p0 = b[-step];
-  const int q0 = b[0], q1 = b[step], q2 = b[2 * step], q3 = b[3 * step];
-  const bool mask = !(iabs(p3 - p2) > lim || iabs(p2 - p1) > lim || iabs(p1 - p0) > lim || iabs(q1 - q0) > lim ||
-                      iabs(q2 - q1) > lim || iabs(q3 - q2) > lim || iabs(p0 - q0) * 2 + iabs(p1 - q1) / 2 > blim);
-  bool flat = false, flat2 = false;
+struct TileCfg {
+  // LDS row pitch in samples: odd number of dwords per row for both sample widths, so that the
+  // vertical pass (lane = row) walks its row without bank conflicts
+  static constexpr int TP = sizeof(Pix) == 1 ? 76 : 74;
+};
+
+__device__ __forceinline__ int iabsd(int a, int b) { return (int)__usad((unsigned)a, (unsigned)b, 0u); }
+__device__ __forceinline__ int sclamp(int t, int lo, int hi) { return t < lo ? lo : (t > hi ? hi : t); }
+
+// Filter one line across one edge held in registers: w[0..7] = p7..p0, w[8..15] = q0..q7
+// (only w[4..11] are touched unless kind == 16).  kind 0 = no filter here.
+// vpx_dsp/loopfilter.c: filter_mask :33, flat_mask4 :49, flat_mask5 :62, hev_mask :72,
+// filter4 :76, filter8 :162, filter16 :235; highbd forms :359-447 (thresholds << (bd-8)).
+__device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned thr3, int sh) {
+  // w + q points at q0 (q = 8 for the block edge, 12 for the interior 4x4 edge)
+  if (kind == 0) return;
+  const int blim = (int)(thr3 & 0xff) << sh, lim = (int)((thr3 >> 8) & 0xff) << sh;
+  const int thr = (int)((thr3 >> 16) & 0xff) << sh, one = 1 << sh;
+  const int p3 = w[q - 4], p2 = w[q - 3], p1 = w[q - 2], p0 = w[q - 1];
+  const int q0 = w[q], q1 = w[q + 1], q2 = w[q + 2], q3 = w[q + 3];
+  const int d10 = iabsd(p1, p0), e10 = iabsd(q1, q0);
+  const int m = max(max(max(iabsd(p3, p2), iabsd(p2, p1)), max(d10, e10)), max(iabsd(q2, q1), iabsd(q3, q2)));
+  const bool mask = !(m > lim || iabsd(p0, q0) * 2 + (iabsd(p1, q1) >> 1) > blim);
+  if (!mask) return;  // every filter form leaves the samples unchanged when the mask is off
+  bool flat = false;
   if (kind >= 8)
-    flat = !(iabs(p1 - p0) > one || iabs(q1 - q0) > one || iabs(p2 - p0) > one || iabs(q2 - q0) > one ||
-             iabs(p3 - p0) > one || iabs(q3 - q0) > one);
-  if (kind == 16 && flat && mask) {
-    const int p4 = b[-5 * step], p5 = b[-6 * step], p6 = b[-7 * step], p7 = b[-8 * step];
-    const int q4 = b[4 * step], q5 = b[5 * step], q6 = b[6 * step], q7 = b[7 * step];
-    flat2 = !(iabs(p4 - p0) > one || iabs(q4 - q0) > one || iabs(p5 - p0) > one || iabs(q5 - q0) > one ||
-              iabs(p6 - p0) > one || iabs(q6 - q0) > one || iabs(p7 - p0) > one || iabs(q7 - q0) > one);
-    if (flat2) {
-      // 15-tap [1 1 1 1 1 1 1 2 1 1 1 1 1 1 1] with replication at p7 / q7: sliding sum
-      int s = p7 * 7 + p6 * 2 + p5 + p4 + p3 + p2 + p1 + p0 + q0;
-      b[-7 * step] = (Pix)((s + 8) >> 4);
-      s += q1 - p7 + p5 - p6; b[-6 * step] = (Pix)((s + 8) >> 4);
-      s += q2 - p7 + p4 - p5; b[-5 * step] = (Pix)((s + 8) >> 4);
-      s += q3 - p7 + p3 - p4; b[-4 * step] = (Pix)((s + 8) >> 4);
-      s += q4 - p7 + p2 - p3; b[-3 * step] = (Pix)((s + 8) >> 4);
-      s += q5 - p7 + p1 - p2; b[-2 * step] = (Pix)((s + 8) >> 4);
-      s += q6 - p7 + p0 - p1; b[-1 * step] = (Pix)((s + 8) >> 4);
-      s += q7 - p7 + q0 - p0; b[0] = (Pix)((s + 8) >> 4);
-      s += q7 - p6 + q1 - q0; b[1 * step] = (Pix)((s + 8) >> 4);
-      s += q7 - p5 + q2 - q1; b[2 * step] = (Pix)((s + 8) >> 4);
-      s += q7 - p4 + q3 - q2; b[3 * step] = (Pix)((s + 8) >> 4);
-      s += q7 - p3 + q4 - q3; b[4 * step] = (Pix)((s + 8) >> 4);
-      s += q7 - p2 + q5 - q4; b[5 * step] = (Pix)((s + 8) >> 4);
-      s += q7 - p1 + q6 - q5; b[6 * step] = (Pix)((s + 8) >> 4);
-      return;
+    flat = max(max(max(d10, e10), max(iabsd(p2, p0), iabsd(q2, q0))), max(iabsd(p3, p0), iabsd(q3, q0))) <= one;
+  if (flat) {
+    if (kind == 16) {
+      const int p4 = w[q - 5], p5 = w[q - 6], p6 = w[q - 7], p7 = w[q - 8];
+      const int q4 = w[q + 4], q5 = w[q + 5], q6 = w[q + 6], q7 = w[q + 7];
+      const bool flat2 = max(max(max(iabsd(p4, p0), iabsd(q4, q0)), max(iabsd(p5, p0), iabsd(q5, q0))),
+                             max(max(iabsd(p6, p0), iabsd(q6, q0)), max(iabsd(p7, p0), iabsd(q7, q0)))) <= one;
+      if (flat2) {
+        // 15-tap [1 1 1 1 1 1 1 2 1 1 1 1 1 1 1], replication at p7 / q7: sliding sum
+        int s = p7 * 7 + p6 * 2 + p5 + p4 + p3 + p2 + p1 + p0 + q0 + 8;
+        w[q - 7] = s >> 4;
+        s += q1 - p7 + p5 - p6; w[q - 6] = s >> 4;
+        s += q2 - p7 + p4 - p5; w[q - 5] = s >> 4;
+        s += q3 - p7 + p3 - p4; w[q - 4] = s >> 4;
+        s += q4 - p7 + p2 - p3; w[q - 3] = s >> 4;
+        s += q5 - p7 + p1 - p2; w[q - 2] = s >> 4;
+        s += q6 - p7 + p0 - p1; w[q - 1] = s >> 4;
+        s += q7 - p7 + q0 - p0; w[q] = s >> 4;
+        s += q7 - p6 + q1 - q0; w[q + 1] = s >> 4;
+        s += q7 - p5 + q2 - q1; w[q + 2] = s >> 4;
+        s += q7 - p4 + q3 - q2; w[q + 3] = s >> 4;
+        s += q7 - p3 + q4 - q3; w[q + 4] = s >> 4;
+        s += q7 - p2 + q5 - q4; w[q + 5] = s >> 4;
+        s += q7 - p1 + q6 - q5; w[q + 6] = s >> 4;
+        return;
+      }
     }
-  }
-  if (flat && mask) {
-    // 7-tap [1 1 1 2 1 1 1] with replication at p3 / q3
-    b[-3 * step] = (Pix)((p3 + p3 + p3 + 2 * p2 + p1 + p0 + q0 + 4) >> 3);
-    b[-2 * step] = (Pix)((p3 + p3 + p2 + 2 * p1 + p0 + q0 + q1 + 4) >> 3);
-    b[-1 * step] = (Pix)((p3 + p2 + p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3);
-    b[0] = (Pix)((p2 + p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3);
-    b[1 * step] = (Pix)((p1 + p0 + q0 + 2 * q1 + q2 + q3 + q3 + 4) >> 3);
-    b[2 * step] = (Pix)((p0 + q0 + q1 + 2 * q2 + q3 + q3 + q3 + 4) >> 3);
+    // 7-tap [1 1 1 2 1 1 1], replication at p3 / q3
+    int s = p3 * 3 + p2 * 2 + p1 + p0 + q0 + 4;
+    w[q - 3] = s >> 3;
+    s += q1 - p3 + p1 - p2; w[q - 2] = s >> 3;
+    s += q2 - p3 + p0 - p1; w[q - 1] = s >> 3;
+    s += q3 - p3 + q0 - p0; w[q] = s >> 3;
+    s += q3 - p2 + q1 - q0; w[q + 1] = s >> 3;
+    s += q3 - p1 + q2 - q1; w[q + 2] = s >> 3;
     return;
   }
-  // narrow filter
-  const int off = 0x80 << sh;
-  const int hev = (iabs(p1 - p0) > thr || iabs(q1 - q0) > thr) ? -1 : 0;
+  // narrow filter (filter4)
+  const int off = 0x80 << sh, lo = -off, hi = off - 1;
+  const int hev = (d10 > thr || e10 > thr) ? -1 : 0;
   const int ps1 = p1 - off, ps0 = p0 - off, qs0 = q0 - off, qs1 = q1 - off;
-  int f = sclamp(ps1 - qs1, bd) & hev;
-  f = sclamp(f + 3 * (qs0 - ps0), bd) & (mask ? -1 : 0);
-  const int f1 = sclamp(f + 4, bd) >> 3, f2 = sclamp(f + 3, bd) >> 3;
-  b[0] = (Pix)(sclamp(qs0 - f1, bd) + off);
-  b[-step] = (Pix)(sclamp(ps0 + f2, bd) + off);
+  int f = sclamp(ps1 - qs1, lo, hi) & hev;
+  f = sclamp(f + 3 * (qs0 - ps0), lo, hi);
+  const int f1 = sclamp(f + 4, lo, hi) >> 3, f2 = sclamp(f + 3, lo, hi) >> 3;
+  w[q] = sclamp(qs0 - f1, lo, hi) + off;
+  w[q - 1] = sclamp(ps0 + f2, lo, hi) + off;
   f = ((f1 + 1) >> 1) & ~hev;
-  b[step] = (Pix)(sclamp(qs1 - f, bd) + off);
-  b[-2 * step] = (Pix)(sclamp(ps1 + f, bd) + off);
+  w[q + 1] = sclamp(qs1 - f, lo, hi) + off;
+  w[q - 2] = sclamp(ps1 + f, lo, hi) + off;
 }
 
-template <typename Pix>
-__global__ __launch_bounds__(64) void lf_diag_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int t,
-                                                     int r_min, LfThreshDev th, FrameDev f, int mi_rows) {
-  __shared__ Pix tile[72 * TP];
-  __shared__ uint8_t lvl[64];
+// One (superblock, plane): N = 64 (luma) or 32 (4:2:0 chroma) samples per side.
+template <typename Pix, int N>
+__device__ __forceinline__ void lf_sb_body(Pix *tile, uint8_t *lvl, unsigned *thr3, const vp9hip_lfm &m, int sr,
+                                           int sc, int pl, const LfThreshDev &th, const FrameDev &f, int mi_rows) {
+  constexpr int TP = TileCfg<Pix>::TP;
+  constexpr int PPD = 4 / sizeof(Pix);  // samples per dword
   const int lane = threadIdx.x;
-  const int sr = r_min + blockIdx.x, sc = t - 2 * sr;
-  const int pl = blockIdx.y;
-  const vp9hip_lfm &m = lfms[sr * sb_cols + sc];
-  const int bd = f.bit_depth;
-  const int ss = pl ? 1 : 0;
-  const int n = 64 >> ss;           // samples per superblock side in this plane
-  const int ncol = 8 >> ss;         // mask columns per mask row
+  const int sh = f.bit_depth - 8;
+  constexpr int n = N;         // samples per superblock side in this plane
+  constexpr int ncol = N / 8;  // mask columns per mask row
   const int x0 = sc * n, y0 = sr * n;
   Pix *plane = (Pix *)f.plane[pl];
   const int stride = f.stride[pl];
@@ -132,84 +135,117 @@ __global__ __launch_bounds__(64) void lf_diag_kernel(const vp9hip_lfm *__restric
     // lfl_uv[(r>>1)*4 + c] = lfl_y[r*8 + 2c] for even mi rows r (vp9_loopfilter.c:1344-1348)
     if (lane < 16) lvl[lane] = m.lfl_y[(lane >> 2) * 16 + (lane & 3) * 2];
   }
-  // stage tile: rows y0-8 .. y0+n-1, cols x0-8 .. x0+n-1 (clipped to the plane)
-  const int tw = n + 8, thh = n + 8;
-  for (int i = lane; i < tw * thh; i += 64) {
-    const int r = i / tw, c = i - r * tw;
-    const int gx = x0 - 8 + c, gy = y0 - 8 + r;
-    Pix v = 0;
-    if (gx >= 0 && gy >= 0 && gx < pw && gy < ph) v = plane[(size_t)gy * stride + gx];
-    tile[r * TP + c] = v;
+  thr3[lane] = th.mblim[lane] | (th.lim[lane] << 8) | (th.hev_thr[lane] << 16);
+
+  // stage tile with dword accesses: rows y0-8 .. y0+n-1, cols x0-8 .. x0+n-1 (clipped)
+  constexpr int tw = n + 8;           // samples per tile row
+  constexpr int dpr = tw / PPD;       // dwords per tile row
+  unsigned *tile32 = (unsigned *)tile;
+  constexpr int TPD = TP / PPD;       // LDS pitch in dwords
+  for (int i = lane; i < dpr * tw; i += 64) {
+    const int r = i / dpr, d = i - r * dpr;
+    const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
+    if (gx >= 0 && gy >= 0 && gx < pw && gy < ph)
+      tile32[r * TPD + d] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
   }
   __syncthreads();
 
-  // ---- vertical edges: lane = sample row
-  if (lane < n && y0 + lane < ph) {
-    const int mr = lane >> 3;  // mask row
-    if (mr < mrows) {
-      Pix *row = tile + (8 + lane) * TP + 8;
-      for (int c = 0; c < ncol; ++c) {
-        const int bit = mr * ncol + c;
-        int level = lvl[bit];
-        Pix *b = row + c * 8;
-        if ((l16 >> bit) & 1) {
-          // dual-16 applies the even mask row's thresholds to both rows of the pair
-          int lv = level;
-          if ((mr & 1) && ((l16 >> (bit - ncol)) & 1)) lv = lvl[bit - ncol];
-          filter_edge<Pix>(b, 1, 16, th.mblim[lv], th.lim[lv], th.hev_thr[lv], bd);
-        }
-        if ((l8 >> bit) & 1) filter_edge<Pix>(b, 1, 8, th.mblim[level], th.lim[level], th.hev_thr[level], bd);
-        if ((l4 >> bit) & 1) filter_edge<Pix>(b, 1, 4, th.mblim[level], th.lim[level], th.hev_thr[level], bd);
-        if ((mint >> bit) & 1)
-          filter_edge<Pix>(b + 4, 1, 4, th.mblim[level], th.lim[level], th.hev_thr[level], bd);
-      }
+  // ---- vertical edges: lane = sample row; a 16-sample window slides along the row
+  if (lane < n && y0 + lane < ph && (lane >> 3) < mrows) {
+    const int mr = lane >> 3;
+    Pix *row = tile + (8 + lane) * TP;
+    int w[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = row[k];
+    for (int c = 0; c < ncol; ++c) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[8 + k] = row[8 + c * 8 + k];
+      const int bit = mr * ncol + c;
+      const int level = lvl[bit];
+      const int kind = ((l16 >> bit) & 1) ? 16 : ((l8 >> bit) & 1) ? 8 : ((l4 >> bit) & 1) ? 4 : 0;
+      int lv = level;
+      // vpx_lpf_vertical_16_dual applies the even mask row's thresholds to both rows of a pair
+      if (kind == 16 && (mr & 1) && ((l16 >> (bit - ncol)) & 1)) lv = lvl[bit - ncol];
+      filter_window(w, 8, kind, thr3[lv], sh);
+      filter_window(w, 12, ((mint >> bit) & 1) ? 4 : 0, thr3[level], sh);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) row[c * 8 + k] = (Pix)w[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[k] = w[8 + k];
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) row[ncol * 8 + k] = (Pix)w[k];
   }
   __syncthreads();
 
-  // ---- horizontal edges: lane = sample column
+  // ---- horizontal edges: lane = sample column; the window slides down the column
   if (lane < n && x0 + lane < pw) {
     const int c = lane >> 3;  // mask column
-    // position of this column's segment inside a run of 16-wide segments decides whose
-    // thresholds a "dual" call used (vp9_loopfilter.c:466-469)
-    int skip_int = -1;
+    int skip_int = -1;        // skip_border_4x4_r (vp9_loopfilter.c:1385-1387)
     if (pl)
       for (int r = 0; r < rows_mi; r += 2)
         if (mi_row + r == mi_rows - 1) skip_int = r >> 1;
+    Pix *col = tile + 8 + lane;
+    int w[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = col[k * TP];
     for (int mr = 0; mr < mrows; ++mr) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[8 + k] = col[(8 + mr * 8 + k) * TP];
       const bool edge_ok = !(mi_row == 0 && mr == 0);
       const int bit = mr * ncol + c;
       const int level = lvl[bit];
-      Pix *b = tile + (8 + mr * 8) * TP + 8 + lane;
-      const uint64_t rowmask16 = edge_ok ? ((a16 >> (mr * ncol)) & ((1u << ncol) - 1)) : 0;
-      const bool b16 = (rowmask16 >> c) & 1;
-      const bool b8 = edge_ok && ((a8 >> bit) & 1), b4 = edge_ok && ((a4 >> bit) & 1);
-      const bool bi = (mr != skip_int) && ((mint >> bit) & 1);
-      if (b16) {
-        int run = 0;  // number of consecutive 16-wide segments immediately to the left
+      const unsigned rowmask16 = edge_ok ? (unsigned)((a16 >> (mr * ncol)) & ((1u << ncol) - 1)) : 0u;
+      int kind = 0, lv = level;
+      if ((rowmask16 >> c) & 1) {
+        kind = 16;
+        // the second segment of a 16-wide "dual" pair reuses the first's thresholds
+        // (vp9_loopfilter.c:466-469); pairs form from the start of a run of 16-wide segments
+        int run = 0;
         for (int k = c - 1; k >= 0 && ((rowmask16 >> k) & 1); --k) ++run;
-        const int lv = (run & 1) ? lvl[bit - 1] : level;
-        filter_edge<Pix>(b, TP, 16, th.mblim[lv], th.lim[lv], th.hev_thr[lv], bd);
-      } else if (b8) {
-        filter_edge<Pix>(b, TP, 8, th.mblim[level], th.lim[level], th.hev_thr[level], bd);
-        if (bi) filter_edge<Pix>(b + 4 * TP, TP, 4, th.mblim[level], th.lim[level], th.hev_thr[level], bd);
-      } else if (b4) {
-        filter_edge<Pix>(b, TP, 4, th.mblim[level], th.lim[level], th.hev_thr[level], bd);
-        if (bi) filter_edge<Pix>(b + 4 * TP, TP, 4, th.mblim[level], th.lim[level], th.hev_thr[level], bd);
-      } else if (bi) {
-        filter_edge<Pix>(b + 4 * TP, TP, 4, th.mblim[level], th.lim[level], th.hev_thr[level], bd);
+        if (run & 1) lv = lvl[bit - 1];
+      } else if (edge_ok && ((a8 >> bit) & 1)) {
+        kind = 8;
+      } else if (edge_ok && ((a4 >> bit) & 1)) {
+        kind = 4;
       }
+      filter_window(w, 8, kind, thr3[lv], sh);
+      // the 16-wide branch of filter_selectively_horiz never filters the interior edge (:465-538)
+      const bool bi = kind != 16 && (mr != skip_int) && ((mint >> bit) & 1);
+      filter_window(w, 12, bi ? 4 : 0, thr3[level], sh);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) col[(mr * 8 + k) * TP] = (Pix)w[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[k] = w[8 + k];
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col[(mrows * 8 + k) * TP] = (Pix)w[k];
   }
   __syncthreads();
 
-  // write the tile back (everything except the untouched top-left 8x8 corner)
-  for (int i = lane; i < tw * thh; i += 64) {
-    const int r = i / tw, c = i - r * tw;
-    if (r < 8 && c < 8) continue;
-    const int gx = x0 - 8 + c, gy = y0 - 8 + r;
-    if (gx >= 0 && gy >= 0 && gx < pw && gy < ph) plane[(size_t)gy * stride + gx] = tile[r * TP + c];
+  // write the tile back (the top-left 8x8 corner belongs to nobody here)
+  for (int i = lane; i < dpr * tw; i += 64) {
+    const int r = i / dpr, d = i - r * dpr;
+    if (r < 8 && d * PPD < 8) continue;
+    const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
+    if (gx >= 0 && gy >= 0 && gx < pw && gy < ph)
+      *(unsigned *)(plane + (size_t)gy * stride + gx) = tile32[r * TPD + d];
   }
+}
+
+template <typename Pix>
+__global__ __launch_bounds__(64) void lf_diag_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int t,
+                                                     int r_min, LfThreshDev th, FrameDev f, int mi_rows) {
+  __shared__ __attribute__((aligned(16))) Pix tile[72 * TileCfg<Pix>::TP];
+  __shared__ uint8_t lvl[64];
+  __shared__ unsigned thr3[64];
+  const int sr = r_min + blockIdx.x, sc = t - 2 * sr;
+  const int pl = blockIdx.y;
+  const vp9hip_lfm &m = lfms[sr * sb_cols + sc];
+  if (pl == 0)
+    lf_sb_body<Pix, 64>(tile, lvl, thr3, m, sr, sc, pl, th, f, mi_rows);
+  else
+    lf_sb_body<Pix, 32>(tile, lvl, thr3, m, sr, sc, pl, th, f, mi_rows);
 }
 
 }  // namespace
