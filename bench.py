@@ -124,13 +124,9 @@ def main():
                                       f"run) through oracle/ C restatement, single thread, {t_cpu:.1f} s"}
 
     # stats reduce: total frames (sum) and slowest rank (max) — the only collective in the harness
-    frames_total, t_max = float(args.steps), elapsed
-    if dist is not None:
-        v = torch.tensor([float(args.steps), 0.0], device="cuda", dtype=torch.float64)
-        dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        m = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        frames_total, t_max = float(v[0].item()), float(m[0].item())
+    import cuda_vp9_amd.batch as batch
+    frames_total, _, t_max = batch.reduce_stats(dist, args.steps, 0.0, elapsed,
+                                                device=torch.device("cuda", local_rank))
 
     if rank == 0:
         kernels = {}
