@@ -202,9 +202,10 @@ class Context:
         self.check(lib().vp9hip_idct_add_batch(self.handle, ctypes.c_void_p(d_blocks.ptr), sc,
                                                ctypes.c_void_p(d_coeffs.ptr), ctypes.byref(frame.desc)))
 
-    def inter_pred_batch(self, d_tasks, n_tasks, refs, dst):
+    def inter_pred_batch(self, d_tasks, class_count, refs, dst):
         arr = (Frame * len(refs))(*[r.desc for r in refs])
-        self.check(lib().vp9hip_inter_pred_batch(self.handle, ctypes.c_void_p(d_tasks.ptr), int(n_tasks),
+        cc = (ctypes.c_int32 * 6)(*[int(v) for v in class_count])
+        self.check(lib().vp9hip_inter_pred_batch(self.handle, ctypes.c_void_p(d_tasks.ptr), cc,
                                                  arr, len(refs), ctypes.byref(dst.desc)))
 
     def intra_pred_waves(self, d_tasks, wave_start, d_coeffs, frame):
@@ -223,6 +224,18 @@ class Context:
         if self.handle:
             lib().vp9hip_destroy(self.handle)
             self.handle = None
+
+
+def sort_inter_tasks(tasks, hbd):
+    """Group inter tasks into the six classes vp9hip_inter_pred_batch takes."""
+    unscaled = (tasks["step_x"] == 16).all(axis=1) & (tasks["step_y"] == 16).all(axis=1)
+    cls = np.full(len(tasks), 5, np.int32)
+    if not hbd:
+        # fast classes cover the VP9 block shapes: width W with height <= HMAX(W), multiple of 4
+        for k, (w, hmax) in enumerate(((4, 8), (8, 16), (16, 32), (32, 64), (64, 64))):
+            cls[unscaled & (tasks["w"] == w) & (tasks["h"] <= hmax) & (tasks["h"] % 4 == 0)] = k
+    order = np.argsort(cls, kind="stable")
+    return tasks[order], [int((cls == k).sum()) for k in range(6)]
 
 
 def sort_txb_by_size(blocks):

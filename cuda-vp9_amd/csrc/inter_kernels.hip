@@ -17,48 +17,51 @@ namespace {
 
 // vp9/common/vp9_filter.c:14-82, in INTERP_FILTER order (vp9_filter.h:23-28):
 // EIGHTTAP, EIGHTTAP_SMOOTH, EIGHTTAP_SHARP, BILINEAR, FOURTAP.
-__device__ const int16_t kFilters[5][16][8] = {
-  { { 0, 0, 0, 128, 0, 0, 0, 0 },        { 0, 1, -5, 126, 8, -3, 1, 0 },
-    { -1, 3, -10, 122, 18, -6, 2, 0 },   { -1, 4, -13, 118, 27, -9, 3, -1 },
-    { -1, 4, -16, 112, 37, -11, 4, -1 }, { -1, 5, -18, 105, 48, -14, 4, -1 },
-    { -1, 5, -19, 97, 58, -16, 5, -1 },  { -1, 6, -19, 88, 68, -18, 5, -1 },
-    { -1, 6, -19, 78, 78, -19, 6, -1 },  { -1, 5, -18, 68, 88, -19, 6, -1 },
-    { -1, 5, -16, 58, 97, -19, 5, -1 },  { -1, 4, -14, 48, 105, -18, 5, -1 },
-    { -1, 4, -11, 37, 112, -16, 4, -1 }, { -1, 3, -9, 27, 118, -13, 4, -1 },
-    { 0, 2, -6, 18, 122, -10, 3, -1 },   { 0, 1, -3, 8, 126, -5, 1, 0 } },
-  { { 0, 0, 0, 128, 0, 0, 0, 0 },       { -3, -1, 32, 64, 38, 1, -3, 0 },
-    { -2, -2, 29, 63, 41, 2, -3, 0 },   { -2, -2, 26, 63, 43, 4, -4, 0 },
-    { -2, -3, 24, 62, 46, 5, -4, 0 },   { -2, -3, 21, 60, 49, 7, -4, 0 },
-    { -1, -4, 18, 59, 51, 9, -4, 0 },   { -1, -4, 16, 57, 53, 12, -4, -1 },
-    { -1, -4, 14, 55, 55, 14, -4, -1 }, { -1, -4, 12, 53, 57, 16, -4, -1 },
-    { 0, -4, 9, 51, 59, 18, -4, -1 },   { 0, -4, 7, 49, 60, 21, -3, -2 },
-    { 0, -4, 5, 46, 62, 24, -3, -2 },   { 0, -4, 4, 43, 63, 26, -2, -2 },
-    { 0, -3, 2, 41, 63, 29, -2, -2 },   { 0, -3, 1, 38, 64, 32, -1, -3 } },
-  { { 0, 0, 0, 128, 0, 0, 0, 0 },         { -1, 3, -7, 127, 8, -3, 1, 0 },
-    { -2, 5, -13, 125, 17, -6, 3, -1 },   { -3, 7, -17, 121, 27, -10, 5, -2 },
-    { -4, 9, -20, 115, 37, -13, 6, -2 },  { -4, 10, -23, 108, 48, -16, 8, -3 },
-    { -4, 10, -24, 100, 59, -19, 9, -3 }, { -4, 11, -24, 90, 70, -21, 10, -4 },
-    { -4, 11, -23, 80, 80, -23, 11, -4 }, { -4, 10, -21, 70, 90, -24, 11, -4 },
-    { -3, 9, -19, 59, 100, -24, 10, -4 }, { -3, 8, -16, 48, 108, -23, 10, -4 },
-    { -2, 6, -13, 37, 115, -20, 9, -4 },  { -2, 5, -10, 27, 121, -17, 7, -3 },
-    { -1, 3, -6, 17, 125, -13, 5, -2 },   { 0, 1, -3, 8, 127, -7, 3, -1 } },
-  { { 0, 0, 0, 128, 0, 0, 0, 0 },  { 0, 0, 0, 120, 8, 0, 0, 0 },
-    { 0, 0, 0, 112, 16, 0, 0, 0 }, { 0, 0, 0, 104, 24, 0, 0, 0 },
-    { 0, 0, 0, 96, 32, 0, 0, 0 },  { 0, 0, 0, 88, 40, 0, 0, 0 },
-    { 0, 0, 0, 80, 48, 0, 0, 0 },  { 0, 0, 0, 72, 56, 0, 0, 0 },
-    { 0, 0, 0, 64, 64, 0, 0, 0 },  { 0, 0, 0, 56, 72, 0, 0, 0 },
-    { 0, 0, 0, 48, 80, 0, 0, 0 },  { 0, 0, 0, 40, 88, 0, 0, 0 },
-    { 0, 0, 0, 32, 96, 0, 0, 0 },  { 0, 0, 0, 24, 104, 0, 0, 0 },
-    { 0, 0, 0, 16, 112, 0, 0, 0 }, { 0, 0, 0, 8, 120, 0, 0, 0 } },
-  { { 0, 0, 0, 128, 0, 0, 0, 0 },     { 0, 0, -4, 126, 8, -2, 0, 0 },
-    { 0, 0, -6, 120, 18, -4, 0, 0 },  { 0, 0, -8, 114, 28, -6, 0, 0 },
-    { 0, 0, -10, 108, 36, -6, 0, 0 }, { 0, 0, -12, 102, 46, -8, 0, 0 },
-    { 0, 0, -12, 94, 56, -10, 0, 0 }, { 0, 0, -12, 84, 66, -10, 0, 0 },
-    { 0, 0, -12, 76, 76, -12, 0, 0 }, { 0, 0, -10, 66, 84, -12, 0, 0 },
-    { 0, 0, -10, 56, 94, -12, 0, 0 }, { 0, 0, -8, 46, 102, -12, 0, 0 },
-    { 0, 0, -6, 36, 108, -10, 0, 0 }, { 0, 0, -6, 28, 114, -8, 0, 0 },
-    { 0, 0, -4, 18, 120, -6, 0, 0 },  { 0, 0, -2, 8, 126, -4, 0, 0 } }
-};
+#define VP9HIP_FILTER_TABLE { \
+  { { 0, 0, 0, 128, 0, 0, 0, 0 },        { 0, 1, -5, 126, 8, -3, 1, 0 }, \
+    { -1, 3, -10, 122, 18, -6, 2, 0 },   { -1, 4, -13, 118, 27, -9, 3, -1 }, \
+    { -1, 4, -16, 112, 37, -11, 4, -1 }, { -1, 5, -18, 105, 48, -14, 4, -1 }, \
+    { -1, 5, -19, 97, 58, -16, 5, -1 },  { -1, 6, -19, 88, 68, -18, 5, -1 }, \
+    { -1, 6, -19, 78, 78, -19, 6, -1 },  { -1, 5, -18, 68, 88, -19, 6, -1 }, \
+    { -1, 5, -16, 58, 97, -19, 5, -1 },  { -1, 4, -14, 48, 105, -18, 5, -1 }, \
+    { -1, 4, -11, 37, 112, -16, 4, -1 }, { -1, 3, -9, 27, 118, -13, 4, -1 }, \
+    { 0, 2, -6, 18, 122, -10, 3, -1 },   { 0, 1, -3, 8, 126, -5, 1, 0 } }, \
+  { { 0, 0, 0, 128, 0, 0, 0, 0 },       { -3, -1, 32, 64, 38, 1, -3, 0 }, \
+    { -2, -2, 29, 63, 41, 2, -3, 0 },   { -2, -2, 26, 63, 43, 4, -4, 0 }, \
+    { -2, -3, 24, 62, 46, 5, -4, 0 },   { -2, -3, 21, 60, 49, 7, -4, 0 }, \
+    { -1, -4, 18, 59, 51, 9, -4, 0 },   { -1, -4, 16, 57, 53, 12, -4, -1 }, \
+    { -1, -4, 14, 55, 55, 14, -4, -1 }, { -1, -4, 12, 53, 57, 16, -4, -1 }, \
+    { 0, -4, 9, 51, 59, 18, -4, -1 },   { 0, -4, 7, 49, 60, 21, -3, -2 }, \
+    { 0, -4, 5, 46, 62, 24, -3, -2 },   { 0, -4, 4, 43, 63, 26, -2, -2 }, \
+    { 0, -3, 2, 41, 63, 29, -2, -2 },   { 0, -3, 1, 38, 64, 32, -1, -3 } }, \
+  { { 0, 0, 0, 128, 0, 0, 0, 0 },         { -1, 3, -7, 127, 8, -3, 1, 0 }, \
+    { -2, 5, -13, 125, 17, -6, 3, -1 },   { -3, 7, -17, 121, 27, -10, 5, -2 }, \
+    { -4, 9, -20, 115, 37, -13, 6, -2 },  { -4, 10, -23, 108, 48, -16, 8, -3 }, \
+    { -4, 10, -24, 100, 59, -19, 9, -3 }, { -4, 11, -24, 90, 70, -21, 10, -4 }, \
+    { -4, 11, -23, 80, 80, -23, 11, -4 }, { -4, 10, -21, 70, 90, -24, 11, -4 }, \
+    { -3, 9, -19, 59, 100, -24, 10, -4 }, { -3, 8, -16, 48, 108, -23, 10, -4 }, \
+    { -2, 6, -13, 37, 115, -20, 9, -4 },  { -2, 5, -10, 27, 121, -17, 7, -3 }, \
+    { -1, 3, -6, 17, 125, -13, 5, -2 },   { 0, 1, -3, 8, 127, -7, 3, -1 } }, \
+  { { 0, 0, 0, 128, 0, 0, 0, 0 },  { 0, 0, 0, 120, 8, 0, 0, 0 }, \
+    { 0, 0, 0, 112, 16, 0, 0, 0 }, { 0, 0, 0, 104, 24, 0, 0, 0 }, \
+    { 0, 0, 0, 96, 32, 0, 0, 0 },  { 0, 0, 0, 88, 40, 0, 0, 0 }, \
+    { 0, 0, 0, 80, 48, 0, 0, 0 },  { 0, 0, 0, 72, 56, 0, 0, 0 }, \
+    { 0, 0, 0, 64, 64, 0, 0, 0 },  { 0, 0, 0, 56, 72, 0, 0, 0 }, \
+    { 0, 0, 0, 48, 80, 0, 0, 0 },  { 0, 0, 0, 40, 88, 0, 0, 0 }, \
+    { 0, 0, 0, 32, 96, 0, 0, 0 },  { 0, 0, 0, 24, 104, 0, 0, 0 }, \
+    { 0, 0, 0, 16, 112, 0, 0, 0 }, { 0, 0, 0, 8, 120, 0, 0, 0 } }, \
+  { { 0, 0, 0, 128, 0, 0, 0, 0 },     { 0, 0, -4, 126, 8, -2, 0, 0 }, \
+    { 0, 0, -6, 120, 18, -4, 0, 0 },  { 0, 0, -8, 114, 28, -6, 0, 0 }, \
+    { 0, 0, -10, 108, 36, -6, 0, 0 }, { 0, 0, -12, 102, 46, -8, 0, 0 }, \
+    { 0, 0, -12, 94, 56, -10, 0, 0 }, { 0, 0, -12, 84, 66, -10, 0, 0 }, \
+    { 0, 0, -12, 76, 76, -12, 0, 0 }, { 0, 0, -10, 66, 84, -12, 0, 0 }, \
+    { 0, 0, -10, 56, 94, -12, 0, 0 }, { 0, 0, -8, 46, 102, -12, 0, 0 }, \
+    { 0, 0, -6, 36, 108, -10, 0, 0 }, { 0, 0, -6, 28, 114, -8, 0, 0 }, \
+    { 0, 0, -4, 18, 120, -6, 0, 0 },  { 0, 0, -2, 8, 126, -4, 0, 0 } } \
+}
+__device__ const int16_t kFilters[5][16][8] = VP9HIP_FILTER_TABLE;
+static const int16_t kFiltersHost[5][16][8] = VP9HIP_FILTER_TABLE;
+
 
 struct RefSet {
   FrameDev f[VP9HIP_MAX_REFS];
@@ -157,12 +160,217 @@ __global__ __launch_bounds__(64) void inter_pred_kernel(const vp9hip_inter_task 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: 8-bit samples, unscaled references (step 16).  Tasks are grouped by width class on
+// the host (W = 4, 8, 16, 32, 64); a task occupies a SLOT of SL lanes, 64/SL tasks per wave.
+//
+//  stage   (h+7) x (W+8) window -> LDS, 8/16-byte chunks (clamped byte path at frame edges);
+//          window column 0 is source column x0-4 so that output dword j needs window dwords
+//          j, j+1, j+2
+//  rows    lane = (window row, output dword): 4 outputs from 3 dwords with v_alignbyte_b32 +
+//          2 x v_dot4_i32_i8 each (samples biased by -128 to fit i8: sum += 128*128), clipped,
+//          written TRANSPOSED to LDS (T[column][row]) so that the column pass has the same shape
+//  cols    lane = (column, output row dword): 3 dwords of T, same alignbyte/dot4 form, result
+//          clipped and stored (or averaged into dst for the second reference of a compound block)
+// Phase 0 kernels ({0,0,0,128,0,0,0,0}) do not fit i8 and are the identity: handled as copies.
+template <int W>
+struct FastCfg {
+  // A task of width class W is cut into tiles of TW x <=16 outputs; one tile per SLOT of SL lanes.
+  static constexpr int TW = W >= 16 ? 16 : W;                    // tile width
+  static constexpr int HMAX = W == 4 ? 8 : (W == 8 ? 16 : (W == 16 ? 32 : 64));
+  static constexpr int TPT = (W / TW) * (HMAX / 16 ? HMAX / 16 : 1);  // tiles per task (max)
+  static constexpr int SL = TW == 16 ? 64 : (TW == 8 ? 32 : 16);  // lanes per tile
+  static constexpr int G = 64 / SL;                               // tiles per wave
+  static constexpr int DC = TW / 4;                               // output dwords per row
+  static constexpr int CH = TW == 16 ? 16 : 8;                    // staging chunk bytes
+  static constexpr int NCH = (TW + 12 + CH - 1) / CH;             // chunks per window row
+  static constexpr int PW = NCH * CH;                             // window pitch (bytes)
+  static constexpr int PT = 28;                                   // transposed pitch (bytes): 23 rows + pad
+  static constexpr int WIN_BYTES = 23 * PW;
+  static constexpr int T_BYTES = TW * PT;
+  static constexpr int SLOT_BYTES = (WIN_BYTES + T_BYTES + 15) & ~15;
+};
+
+__device__ __forceinline__ int dot8(unsigned lo, unsigned hi, unsigned flo, unsigned fhi) {
+  // 16384 = 128 * sum(taps) undoes the -128 bias of the samples; 64 = rounding
+  int s = __builtin_amdgcn_sdot4((int)lo, (int)flo, 16384 + 64, false);
+  s = __builtin_amdgcn_sdot4((int)hi, (int)fhi, s, false);
+  s >>= 7;
+  return s < 0 ? 0 : (s > 255 ? 255 : s);
+}
+
+template <int W>
+__global__ __launch_bounds__(64) void inter_fast_kernel(const vp9hip_inter_task *__restrict__ tasks, int n_tasks,
+                                                        RefSet refs, FrameDev dstf,
+                                                        const unsigned *__restrict__ taps) {
+  typedef FastCfg<W> C;
+  constexpr int TW = C::TW;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[C::G * C::SLOT_BYTES];
+  const int lane = threadIdx.x;
+  const int g = lane / C::SL, sl = lane % C::SL;
+  const int wid = blockIdx.x * C::G + g;
+  const int ti = wid / C::TPT, tile = wid - ti * C::TPT;
+  const int tx = tile % (W / TW), ty = tile / (W / TW);
+  bool active = ti < n_tasks;
+  vp9hip_inter_task t;
+  if (active) t = tasks[ti];
+  active = active && ty * 16 < t.h;
+  unsigned char *win = lds + g * C::SLOT_BYTES;
+  unsigned char *T = win + C::WIN_BYTES;
+  const int plane = active ? t.plane : 0;
+  const int h = active ? min(16, (int)t.h - ty * 16) : 0;  // tile height: 4, 8 or 16
+  const int filt = active ? (t.flags >> 1) & 7 : 0;
+  const int nref = active ? ((t.flags & 1) ? 2 : 1) : 0;
+  unsigned char *dplane = (unsigned char *)dstf.plane[plane];
+  const int dstride = dstf.stride[plane];
+  const int dx = active ? t.dst_x + tx * TW : 0, dy = active ? t.dst_y + ty * 16 : 0;
+  const int vis_w = active ? min(TW, dstf.awidth[plane] - dx) : 0;
+  const int vis_h = active ? min(h, dstf.aheight[plane] - dy) : 0;
+  const int rows = h + 7;
+
+  for (int r = 0; r < 2; ++r) {  // uniform trip count: barriers inside
+    const bool on = active && r < nref && vis_w > 0 && vis_h > 0;
+    int x0 = 0, y0 = 0, subx = 0, suby = 0;
+    if (on) {
+      const int px = t.pos_x[r] + tx * TW * 16, py = t.pos_y[r] + ty * 16 * 16;
+      x0 = px >> 4;
+      y0 = py >> 4;
+      subx = px & 15;
+      suby = py & 15;
+    }
+    if (on) {
+      const FrameDev &rf = refs.f[t.ref[r]];
+      const unsigned char *src = (const unsigned char *)rf.plane[plane];
+      const int sstride = rf.stride[plane];
+      const int fw = rf.width[plane], fh = rf.height[plane];
+      const bool interior = x0 - 4 >= 0 && x0 + TW + 4 <= fw - 1 && x0 - 4 + C::PW <= sstride && y0 - 3 >= 0 &&
+                            y0 + h + 4 <= fh - 1;
+      if (interior) {
+        const unsigned char *base = src + (size_t)(y0 - 3) * sstride + (x0 - 4);
+        for (int i = sl; i < rows * C::NCH; i += C::SL) {
+          const int rr = i / C::NCH, ch = i - rr * C::NCH;
+          const unsigned char *p = base + (size_t)rr * sstride + ch * C::CH;
+          if constexpr (C::CH == 16) {
+            uint4 v;
+            __builtin_memcpy(&v, p, 16);
+            *(uint4 *)(win + rr * C::PW + ch * 16) = v;
+          } else {
+            uint2 v;
+            __builtin_memcpy(&v, p, 8);
+            *(uint2 *)(win + rr * C::PW + ch * 8) = v;
+          }
+        }
+      } else {
+        for (int i = sl; i < rows * (TW + 12); i += C::SL) {
+          const int rr = i / (TW + 12), cc = i - rr * (TW + 12);
+          int sx = x0 - 4 + cc, sy = y0 - 3 + rr;
+          sx = sx < 0 ? 0 : (sx > fw - 1 ? fw - 1 : sx);
+          sy = sy < 0 ? 0 : (sy > fh - 1 ? fh - 1 : sy);
+          win[rr * C::PW + cc] = src[(size_t)sy * sstride + sx];
+        }
+      }
+    }
+    __syncthreads();
+    if (on) {
+      // rows -> T (transposed, clipped)
+      const unsigned flo = taps[(filt * 16 + subx) * 2], fhi = taps[(filt * 16 + subx) * 2 + 1];
+      const unsigned *win32 = (const unsigned *)win;
+      for (int i = sl; i < rows * C::DC; i += C::SL) {
+        const int rr = i / C::DC, j = i - rr * C::DC;
+        const unsigned *wp = win32 + rr * (C::PW / 4) + j;
+        unsigned d0 = wp[0], d1 = wp[1], d2 = wp[2];
+        unsigned o0, o1, o2, o3;
+        if (subx == 0) {
+          o0 = d1 & 0xff; o1 = (d1 >> 8) & 0xff; o2 = (d1 >> 16) & 0xff; o3 = d1 >> 24;
+        } else {
+          d0 ^= 0x80808080u; d1 ^= 0x80808080u; d2 ^= 0x80808080u;
+          o0 = dot8(__builtin_amdgcn_alignbyte(d1, d0, 1), __builtin_amdgcn_alignbyte(d2, d1, 1), flo, fhi);
+          o1 = dot8(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2), flo, fhi);
+          o2 = dot8(__builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 3), flo, fhi);
+          o3 = dot8(d1, d2, flo, fhi);
+        }
+        unsigned char *tp = T + (4 * j) * C::PT + rr;
+        tp[0] = (unsigned char)o0;
+        tp[C::PT] = (unsigned char)o1;
+        tp[2 * C::PT] = (unsigned char)o2;
+        tp[3 * C::PT] = (unsigned char)o3;
+      }
+    }
+    __syncthreads();
+    if (on) {
+      // columns -> destination
+      const unsigned flo = taps[(filt * 16 + suby) * 2], fhi = taps[(filt * 16 + suby) * 2 + 1];
+      const unsigned *T32 = (const unsigned *)T;
+      unsigned char *dst = dplane + (size_t)dy * dstride + dx;
+      for (int i = sl; i < TW * (h >> 2); i += C::SL) {
+        const int m = i / TW, c = i - m * TW;
+        const unsigned *tp = T32 + c * (C::PT / 4) + m;
+        unsigned t0 = tp[0], t1 = tp[1], t2 = tp[2];
+        unsigned o0, o1, o2, o3;
+        if (suby == 0) {  // output row i is intermediate row i + 3
+          o0 = t0 >> 24; o1 = t1 & 0xff; o2 = (t1 >> 8) & 0xff; o3 = (t1 >> 16) & 0xff;
+        } else {
+          t0 ^= 0x80808080u; t1 ^= 0x80808080u; t2 ^= 0x80808080u;
+          o0 = dot8(t0, t1, flo, fhi);
+          o1 = dot8(__builtin_amdgcn_alignbyte(t1, t0, 1), __builtin_amdgcn_alignbyte(t2, t1, 1), flo, fhi);
+          o2 = dot8(__builtin_amdgcn_alignbyte(t1, t0, 2), __builtin_amdgcn_alignbyte(t2, t1, 2), flo, fhi);
+          o3 = dot8(__builtin_amdgcn_alignbyte(t1, t0, 3), __builtin_amdgcn_alignbyte(t2, t1, 3), flo, fhi);
+        }
+        if (c < vis_w) {
+          unsigned char *d = dst + (size_t)(4 * m) * dstride + c;
+          const int y = 4 * m;
+          if (r == 1) {
+            if (y + 0 < vis_h) d[0] = (unsigned char)((d[0] + o0 + 1) >> 1);
+            if (y + 1 < vis_h) d[dstride] = (unsigned char)((d[dstride] + o1 + 1) >> 1);
+            if (y + 2 < vis_h) d[2 * dstride] = (unsigned char)((d[2 * dstride] + o2 + 1) >> 1);
+            if (y + 3 < vis_h) d[3 * dstride] = (unsigned char)((d[3 * dstride] + o3 + 1) >> 1);
+          } else {
+            if (y + 0 < vis_h) d[0] = (unsigned char)o0;
+            if (y + 1 < vis_h) d[dstride] = (unsigned char)o1;
+            if (y + 2 < vis_h) d[2 * dstride] = (unsigned char)o2;
+            if (y + 3 < vis_h) d[3 * dstride] = (unsigned char)o3;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int W>
+int launch_fast(vp9hip_ctx *ctx, const vp9hip_inter_task *tasks, int n, const RefSet &rs, const FrameDev &d) {
+  if (n <= 0) return VP9HIP_OK;
+  const int grid = (n * FastCfg<W>::TPT + FastCfg<W>::G - 1) / FastCfg<W>::G;
+  hipLaunchKernelGGL(inter_fast_kernel<W>, dim3(grid), dim3(64), 0, ctx->stream, tasks, n, rs, d,
+                     (const unsigned *)ctx->d_taps);
+  VP9HIP_CHECK(ctx, hipGetLastError());
+  return VP9HIP_OK;
+}
+
+int upload_taps(vp9hip_ctx *ctx) {
+  if (ctx->d_taps) return VP9HIP_OK;
+  unsigned packed[5][16][2];
+  for (int f = 0; f < 5; ++f)
+    for (int p = 0; p < 16; ++p)
+      for (int half = 0; half < 2; ++half) {
+        unsigned v = 0;
+        for (int k = 0; k < 4; ++k) v |= (unsigned)((uint8_t)(int8_t)kFiltersHost[f][p][half * 4 + k]) << (8 * k);
+        packed[f][p][half] = v;
+      }
+  VP9HIP_CHECK(ctx, hipMalloc(&ctx->d_taps, sizeof(packed)));
+  VP9HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_taps, packed, sizeof(packed), hipMemcpyHostToDevice, ctx->stream));
+  VP9HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return VP9HIP_OK;
+}
+
 }  // namespace
 
-extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task *d_tasks, int n_tasks,
-                                       const vp9hip_frame *refs, int n_refs, const vp9hip_frame *dst) {
+extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task *d_tasks,
+                                       const int32_t class_count[6], const vp9hip_frame *refs, int n_refs,
+                                       const vp9hip_frame *dst) {
   if (!ctx) return VP9HIP_EINVAL;
-  if (!d_tasks || n_tasks < 0 || !refs || n_refs <= 0 || n_refs > VP9HIP_MAX_REFS || !frame_ok(dst))
+  if (!d_tasks || !class_count || !refs || n_refs <= 0 || n_refs > VP9HIP_MAX_REFS || !frame_ok(dst))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_inter_pred_batch: bad argument");
   RefSet rs;
   memset(&rs, 0, sizeof(rs));
@@ -171,12 +379,35 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
       VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_inter_pred_batch: reference %d does not match the destination format", i);
     rs.f[i] = to_dev(&refs[i]);
   }
-  if (n_tasks == 0) return VP9HIP_OK;
+  int fast_total = 0;
+  for (int i = 0; i < 6; ++i) {
+    if (class_count[i] < 0) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_inter_pred_batch: negative class count");
+    if (i < 5) fast_total += class_count[i];
+  }
+  if (fast_total && dst->hbd)
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_inter_pred_batch: width classes 0..4 are for 8-bit frames; put "
+                                    "16-bit tasks in class 5");
   const FrameDev d = to_dev(dst);
-  if (dst->hbd)
-    hipLaunchKernelGGL(inter_pred_kernel<uint16_t>, dim3(n_tasks), dim3(64), 0, ctx->stream, d_tasks, n_tasks, rs, d);
-  else
-    hipLaunchKernelGGL(inter_pred_kernel<uint8_t>, dim3(n_tasks), dim3(64), 0, ctx->stream, d_tasks, n_tasks, rs, d);
-  VP9HIP_CHECK(ctx, hipGetLastError());
+  int rc;
+  if (fast_total && (rc = upload_taps(ctx))) return rc;
+  const vp9hip_inter_task *p = d_tasks;
+  if ((rc = launch_fast<4>(ctx, p, class_count[0], rs, d))) return rc;
+  p += class_count[0];
+  if ((rc = launch_fast<8>(ctx, p, class_count[1], rs, d))) return rc;
+  p += class_count[1];
+  if ((rc = launch_fast<16>(ctx, p, class_count[2], rs, d))) return rc;
+  p += class_count[2];
+  if ((rc = launch_fast<32>(ctx, p, class_count[3], rs, d))) return rc;
+  p += class_count[3];
+  if ((rc = launch_fast<64>(ctx, p, class_count[4], rs, d))) return rc;
+  p += class_count[4];
+  const int n_gen = class_count[5];
+  if (n_gen > 0) {
+    if (dst->hbd)
+      hipLaunchKernelGGL(inter_pred_kernel<uint16_t>, dim3(n_gen), dim3(64), 0, ctx->stream, p, n_gen, rs, d);
+    else
+      hipLaunchKernelGGL(inter_pred_kernel<uint8_t>, dim3(n_gen), dim3(64), 0, ctx->stream, p, n_gen, rs, d);
+    VP9HIP_CHECK(ctx, hipGetLastError());
+  }
   return VP9HIP_OK;
 }

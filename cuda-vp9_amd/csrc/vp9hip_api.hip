@@ -41,6 +41,7 @@ extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->d_taps) (void)hipFree(ctx->d_taps);
   if (ctx->ev_begin) {
     for (int i = 0; i < VP9HIP_TIMER_SLOTS; ++i) {
       if (ctx->ev_begin[i]) (void)hipEventDestroy(ctx->ev_begin[i]);

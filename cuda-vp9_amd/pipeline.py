@@ -19,7 +19,9 @@ class FrameJob:
             fr.upload(planes)
             self.refs.append(fr)
         self.dst = DevFrame(ctx, W, H, bit_depth=bd, hbd=hbd)
-        self.d_inter = ctx.alloc(wl["inter_tasks"]) if len(wl["inter_tasks"]) else None
+        from . import sort_inter_tasks
+        self.inter_sorted, self.inter_counts = sort_inter_tasks(wl["inter_tasks"], hbd)
+        self.d_inter = ctx.alloc(self.inter_sorted) if len(self.inter_sorted) else None
         self.d_txb = ctx.alloc(wl["txb"]) if len(wl["txb"]) else None
         self.d_coeffs = ctx.alloc(wl["coeffs"])
         self.d_intra = ctx.alloc(wl["intra_sorted"]) if len(wl["intra_sorted"]) else None
@@ -36,7 +38,7 @@ class FrameJob:
     def run(self, phases=("inter", "txb", "intra", "lf")):
         wl, ctx = self.wl, self.ctx
         if "inter" in phases and self.d_inter is not None:
-            ctx.inter_pred_batch(self.d_inter, len(wl["inter_tasks"]), self.refs, self.dst)
+            ctx.inter_pred_batch(self.d_inter, self.inter_counts, self.refs, self.dst)
         if "txb" in phases and self.d_txb is not None:
             ctx.idct_add_batch(self.d_txb, wl["txb_counts"], self.d_coeffs, self.dst)
         if "intra" in phases and self.d_intra is not None:

@@ -83,8 +83,9 @@ def run_case(hip, oracle, bd, hbd, seed, W=328, H=200, n_try=400, scaled=True):
             expect[plane] = pad[:ah, :aw].copy()
             tasks.append(t)
     tasks = np.array(tasks, dtype=hip.INTER_DTYPE)
+    tasks, counts = hip.sort_inter_tasks(tasks, hbd)
     d_tasks = ctx.alloc(tasks)
-    ctx.inter_pred_batch(d_tasks, len(tasks), refs, dst)
+    ctx.inter_pred_batch(d_tasks, counts, refs, dst)
     ctx.sync()
     got = dst.download()
     for p in range(3):
