@@ -200,16 +200,19 @@ __device__ __forceinline__ int dot8(unsigned lo, unsigned hi, unsigned flo, unsi
   return s < 0 ? 0 : (s > 255 ? 255 : s);
 }
 
+constexpr int FAST_THREADS = 256;  // 4 waves per workgroup: WG dispatch rate, not work, bounds tiny WGs
+constexpr int FAST_LDS = 7680;  // max over W of (FAST_THREADS / SL) * SLOT_BYTES (W = 4: 16 slots x 480 B)
+
 template <int W>
-__global__ __launch_bounds__(64) void inter_fast_kernel(const vp9hip_inter_task *__restrict__ tasks, int n_tasks,
-                                                        RefSet refs, FrameDev dstf,
-                                                        const unsigned *__restrict__ taps) {
+__device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, const vp9hip_inter_task *__restrict__ tasks,
+                                                int n_tasks, const RefSet &refs, const FrameDev &dstf,
+                                                const unsigned *__restrict__ taps) {
   typedef FastCfg<W> C;
   constexpr int TW = C::TW;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[C::G * C::SLOT_BYTES];
-  const int lane = threadIdx.x;
-  const int g = lane / C::SL, sl = lane % C::SL;
-  const int wid = blockIdx.x * C::G + g;
+  constexpr int GW = FAST_THREADS / C::SL;  // tiles per workgroup
+  static_assert(GW * C::SLOT_BYTES <= FAST_LDS, "LDS budget");
+  const int g = threadIdx.x / C::SL, sl = threadIdx.x % C::SL;
+  const int wid = wg * GW + g;
   const int ti = wid / C::TPT, tile = wid - ti * C::TPT;
   const int tx = tile % (W / TW), ty = tile / (W / TW);
   bool active = ti < n_tasks;
@@ -338,14 +341,34 @@ __global__ __launch_bounds__(64) void inter_fast_kernel(const vp9hip_inter_task 
   }
 }
 
+// All five width classes in one launch: workgroups [wg_start[k], wg_start[k+1]) serve class k.
+struct FastPlan {
+  int wg_start[6];
+  int task_start[5];
+  int task_count[5];
+};
+
+__global__ __launch_bounds__(FAST_THREADS) void inter_fast_kernel(const vp9hip_inter_task *__restrict__ tasks,
+                                                                  FastPlan plan, RefSet refs, FrameDev dstf,
+                                                                  const unsigned *__restrict__ taps) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FAST_LDS];
+  const int b = blockIdx.x;
+  if (b < plan.wg_start[1])
+    inter_fast_body<4>(lds, b - plan.wg_start[0], tasks + plan.task_start[0], plan.task_count[0], refs, dstf, taps);
+  else if (b < plan.wg_start[2])
+    inter_fast_body<8>(lds, b - plan.wg_start[1], tasks + plan.task_start[1], plan.task_count[1], refs, dstf, taps);
+  else if (b < plan.wg_start[3])
+    inter_fast_body<16>(lds, b - plan.wg_start[2], tasks + plan.task_start[2], plan.task_count[2], refs, dstf, taps);
+  else if (b < plan.wg_start[4])
+    inter_fast_body<32>(lds, b - plan.wg_start[3], tasks + plan.task_start[3], plan.task_count[3], refs, dstf, taps);
+  else
+    inter_fast_body<64>(lds, b - plan.wg_start[4], tasks + plan.task_start[4], plan.task_count[4], refs, dstf, taps);
+}
+
 template <int W>
-int launch_fast(vp9hip_ctx *ctx, const vp9hip_inter_task *tasks, int n, const RefSet &rs, const FrameDev &d) {
-  if (n <= 0) return VP9HIP_OK;
-  const int grid = (n * FastCfg<W>::TPT + FastCfg<W>::G - 1) / FastCfg<W>::G;
-  hipLaunchKernelGGL(inter_fast_kernel<W>, dim3(grid), dim3(64), 0, ctx->stream, tasks, n, rs, d,
-                     (const unsigned *)ctx->d_taps);
-  VP9HIP_CHECK(ctx, hipGetLastError());
-  return VP9HIP_OK;
+int fast_wgs(int n) {
+  constexpr int GW = FAST_THREADS / FastCfg<W>::SL;
+  return (n * FastCfg<W>::TPT + GW - 1) / GW;
 }
 
 int upload_taps(vp9hip_ctx *ctx) {
@@ -390,17 +413,24 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
   const FrameDev d = to_dev(dst);
   int rc;
   if (fast_total && (rc = upload_taps(ctx))) return rc;
-  const vp9hip_inter_task *p = d_tasks;
-  if ((rc = launch_fast<4>(ctx, p, class_count[0], rs, d))) return rc;
-  p += class_count[0];
-  if ((rc = launch_fast<8>(ctx, p, class_count[1], rs, d))) return rc;
-  p += class_count[1];
-  if ((rc = launch_fast<16>(ctx, p, class_count[2], rs, d))) return rc;
-  p += class_count[2];
-  if ((rc = launch_fast<32>(ctx, p, class_count[3], rs, d))) return rc;
-  p += class_count[3];
-  if ((rc = launch_fast<64>(ctx, p, class_count[4], rs, d))) return rc;
-  p += class_count[4];
+  const vp9hip_inter_task *p = d_tasks + fast_total;
+  if (fast_total) {
+    FastPlan plan;
+    const int wgs[5] = { fast_wgs<4>(class_count[0]), fast_wgs<8>(class_count[1]), fast_wgs<16>(class_count[2]),
+                         fast_wgs<32>(class_count[3]), fast_wgs<64>(class_count[4]) };
+    int acc_w = 0, acc_t = 0;
+    for (int k = 0; k < 5; ++k) {
+      plan.wg_start[k] = acc_w;
+      plan.task_start[k] = acc_t;
+      plan.task_count[k] = class_count[k];
+      acc_w += wgs[k];
+      acc_t += class_count[k];
+    }
+    plan.wg_start[5] = acc_w;
+    hipLaunchKernelGGL(inter_fast_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d,
+                       (const unsigned *)ctx->d_taps);
+    VP9HIP_CHECK(ctx, hipGetLastError());
+  }
   const int n_gen = class_count[5];
   if (n_gen > 0) {
     if (dst->hbd)
