@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task
     // below bs are identical to the above-only rule (:322-347)
     {
       int take;
-      const bool ext = (bs == 4 && have_right);
+      // bit 3 (raw edges, used by the rtcd twins): take all 2*bs above samples verbatim
+      const bool ext = (bs == 4 && have_right) || (tk.flags & 8);
       if (x + 2 * bs <= fw)
         take = ext ? 2 * bs : bs;
       else if (x + bs <= fw)

@@ -33,7 +33,10 @@ struct TileCfg {
   static constexpr int TP = sizeof(Pix) == 1 ? 76 : 74;
 };
 
-__device__ __forceinline__ int iabsd(int a, int b) { return (int)__usad((unsigned)a, (unsigned)b, 0u); }
+__device__ __forceinline__ int iabsd(int a, int b) {
+  // samples are < 2^16: one v_sad_u16 gives |a - b|
+  return (int)__builtin_amdgcn_sad_u16((unsigned)a, (unsigned)b, 0u);
+}
 __device__ __forceinline__ int sclamp(int t, int lo, int hi) { return t < lo ? lo : (t > hi ? hi : t); }
 
 // Filter one line across one edge held in registers: w[0..7] = p7..p0, w[8..15] = q0..q7
