@@ -283,10 +283,13 @@ __device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, cons
           unsigned char *d = dst + (size_t)(4 * m) * dstride + c;
           const int y = 4 * m;
           if (r == 1) {
-            if (y + 0 < vis_h) d[0] = (unsigned char)((d[0] + o0 + 1) >> 1);
-            if (y + 1 < vis_h) d[dstride] = (unsigned char)((d[dstride] + o1 + 1) >> 1);
-            if (y + 2 < vis_h) d[2 * dstride] = (unsigned char)((d[2 * dstride] + o2 + 1) >> 1);
-            if (y + 3 < vis_h) d[3 * dstride] = (unsigned char)((d[3 * dstride] + o3 + 1) >> 1);
+            // loads first, then stores (see txfm_kernels.hip: avoids 4 serialised round trips)
+            const unsigned e0 = (y + 0 < vis_h) ? d[0] : 0, e1 = (y + 1 < vis_h) ? d[dstride] : 0;
+            const unsigned e2 = (y + 2 < vis_h) ? d[2 * dstride] : 0, e3 = (y + 3 < vis_h) ? d[3 * dstride] : 0;
+            if (y + 0 < vis_h) d[0] = (unsigned char)((e0 + o0 + 1) >> 1);
+            if (y + 1 < vis_h) d[dstride] = (unsigned char)((e1 + o1 + 1) >> 1);
+            if (y + 2 < vis_h) d[2 * dstride] = (unsigned char)((e2 + o2 + 1) >> 1);
+            if (y + 3 < vis_h) d[3 * dstride] = (unsigned char)((e3 + o3 + 1) >> 1);
           } else {
             if (y + 0 < vis_h) d[0] = (unsigned char)o0;
             if (y + 1 < vis_h) d[dstride] = (unsigned char)o1;

@@ -108,15 +108,18 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
 }
 
 // One (superblock, plane): N = 64 (luma) or 32 (4:2:0 chroma) samples per side.
+// ctl: 4 x 64 dwords of LDS: per mask bit the packed (kind << 24 | hev << 16 | lim << 8 | mblim)
+// of the block-edge filter and of the interior 4x4 filter, for the vertical and horizontal pass.
 template <typename Pix, int N>
-__device__ __forceinline__ void lf_sb_body(Pix *tile, uint8_t *lvl, unsigned *thr3, const vp9hip_lfm &m, int sr,
-                                           int sc, int pl, const LfThreshDev &th, const FrameDev &f, int mi_rows) {
+__device__ __forceinline__ void lf_sb_body(Pix *tile, unsigned *ctl, const vp9hip_lfm &m, int sr, int sc, int pl,
+                                           const LfThreshDev &th, const FrameDev &f, int mi_rows) {
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int PPD = 4 / sizeof(Pix);  // samples per dword
   const int lane = threadIdx.x;
   const int sh = f.bit_depth - 8;
   constexpr int n = N;         // samples per superblock side in this plane
   constexpr int ncol = N / 8;  // mask columns per mask row
+  constexpr int nbits = ncol * ncol;
   const int x0 = sc * n, y0 = sr * n;
   Pix *plane = (Pix *)f.plane[pl];
   const int stride = f.stride[pl];
@@ -124,32 +127,92 @@ __device__ __forceinline__ void lf_sb_body(Pix *tile, uint8_t *lvl, unsigned *th
   const int mi_row = sr * 8;
   const int rows_mi = min(8, mi_rows - mi_row);
   const int mrows = pl ? ((rows_mi + 1) >> 1) : rows_mi;  // mask rows of this plane
+  unsigned *vE = ctl, *vI = ctl + 64, *hE = ctl + 128, *hI = ctl + 192;
 
-  uint64_t l16, l8, l4, a16, a8, a4, mint;
-  if (pl == 0) {
-    l16 = m.left_y[2]; l8 = m.left_y[1]; l4 = m.left_y[0];
-    a16 = m.above_y[2]; a8 = m.above_y[1]; a4 = m.above_y[0];
-    mint = m.int_4x4_y;
-    lvl[lane] = m.lfl_y[lane];
-  } else {
-    l16 = m.left_uv[2]; l8 = m.left_uv[1]; l4 = m.left_uv[0];
-    a16 = m.above_uv[2]; a8 = m.above_uv[1]; a4 = m.above_uv[0];
-    mint = m.int_4x4_uv;
-    // lfl_uv[(r>>1)*4 + c] = lfl_y[r*8 + 2c] for even mi rows r (vp9_loopfilter.c:1344-1348)
-    if (lane < 16) lvl[lane] = m.lfl_y[(lane >> 2) * 16 + (lane & 3) * 2];
-  }
-  thr3[lane] = th.mblim[lane] | (th.lim[lane] << 8) | (th.hev_thr[lane] << 16);
-
-  // stage tile with dword accesses: rows y0-8 .. y0+n-1, cols x0-8 .. x0+n-1 (clipped)
-  constexpr int tw = n + 8;           // samples per tile row
-  constexpr int dpr = tw / PPD;       // dwords per tile row
+  // ---- stage the tile: rows y0-8 .. y0+n-1, cols x0-8 .. x0+n-1 (clipped), dword accesses,
+  // all loads issued before the first LDS store
+  constexpr int tw = n + 8;      // samples per tile row
+  constexpr int dpr = tw / PPD;  // dwords per tile row
+  constexpr int total = dpr * tw;
+  constexpr int K = (total + 63) / 64;
   unsigned *tile32 = (unsigned *)tile;
-  constexpr int TPD = TP / PPD;       // LDS pitch in dwords
-  for (int i = lane; i < dpr * tw; i += 64) {
+  constexpr int TPD = TP / PPD;  // LDS pitch in dwords
+  unsigned stage[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = lane + 64 * k;
     const int r = i / dpr, d = i - r * dpr;
     const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
-    if (gx >= 0 && gy >= 0 && gx < pw && gy < ph)
-      tile32[r * TPD + d] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
+    stage[k] = 0;
+    if (i < total && gx >= 0 && gy >= 0 && gx < pw && gy < ph)
+      stage[k] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
+  }
+
+  // ---- per-mask-bit filter controls (lane = mask bit), vp9_loopfilter.c:297-375, 453-544
+  if (lane < nbits) {
+    uint64_t l16, l8, l4, a16, a8, a4, mint;
+    int level, level_left = 0, level_up = 0;
+    const int mr = lane / ncol, c = lane - mr * ncol;
+    if (pl == 0) {
+      l16 = m.left_y[2]; l8 = m.left_y[1]; l4 = m.left_y[0];
+      a16 = m.above_y[2]; a8 = m.above_y[1]; a4 = m.above_y[0];
+      mint = m.int_4x4_y;
+      level = m.lfl_y[lane];
+      if (c > 0) level_left = m.lfl_y[lane - 1];
+      if (mr > 0) level_up = m.lfl_y[lane - ncol];
+    } else {
+      l16 = m.left_uv[2]; l8 = m.left_uv[1]; l4 = m.left_uv[0];
+      a16 = m.above_uv[2]; a8 = m.above_uv[1]; a4 = m.above_uv[0];
+      mint = m.int_4x4_uv;
+      // lfl_uv[(r>>1)*4 + c] = lfl_y[r*8 + 2c] for even mi rows r (vp9_loopfilter.c:1344-1348)
+      level = m.lfl_y[mr * 16 + c * 2];
+      if (c > 0) level_left = m.lfl_y[mr * 16 + (c - 1) * 2];
+      if (mr > 0) level_up = m.lfl_y[(mr - 1) * 16 + c * 2];
+    }
+    auto thr3 = [&](int lv) { return (unsigned)th.mblim[lv] | ((unsigned)th.lim[lv] << 8) | ((unsigned)th.hev_thr[lv] << 16); };
+    const int bit = lane;
+    // vertical pass
+    {
+      const unsigned kind = ((l16 >> bit) & 1) ? 16u : ((l8 >> bit) & 1) ? 8u : ((l4 >> bit) & 1) ? 4u : 0u;
+      int lv = level;
+      // vpx_lpf_vertical_16_dual applies the even mask row's thresholds to both rows of a pair
+      if (kind == 16 && (mr & 1) && ((l16 >> (bit - ncol)) & 1)) lv = level_up;
+      vE[bit] = (kind << 24) | thr3(lv);
+      vI[bit] = (((mint >> bit) & 1) ? (4u << 24) : 0u) | thr3(level);
+    }
+    // horizontal pass
+    {
+      const bool edge_ok = !(mi_row == 0 && mr == 0);
+      const unsigned rowmask16 = edge_ok ? (unsigned)((a16 >> (mr * ncol)) & ((1u << ncol) - 1)) : 0u;
+      unsigned kind = 0;
+      int lv = level;
+      if ((rowmask16 >> c) & 1) {
+        kind = 16;
+        // the second segment of a 16-wide "dual" pair reuses the first's thresholds
+        // (vp9_loopfilter.c:466-469); pairs form from the start of a run of 16-wide segments
+        int run = 0;
+        for (int k = c - 1; k >= 0 && ((rowmask16 >> k) & 1); --k) ++run;
+        if (run & 1) lv = level_left;
+      } else if (edge_ok && ((a8 >> bit) & 1)) {
+        kind = 8;
+      } else if (edge_ok && ((a4 >> bit) & 1)) {
+        kind = 4;
+      }
+      int skip_int = -1;  // skip_border_4x4_r (vp9_loopfilter.c:1385-1387)
+      if (pl)
+        for (int r = 0; r < rows_mi; r += 2)
+          if (mi_row + r == mi_rows - 1) skip_int = r >> 1;
+      // the 16-wide branch of filter_selectively_horiz never filters the interior edge (:465-538)
+      const bool bi = kind != 16 && (mr != skip_int) && ((mint >> bit) & 1);
+      hE[bit] = (kind << 24) | thr3(lv);
+      hI[bit] = (bi ? (4u << 24) : 0u) | thr3(level);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = lane + 64 * k;
+    const int r = i / dpr, d = i - r * dpr;
+    if (i < total) tile32[r * TPD + d] = stage[k];
   }
   __syncthreads();
 
@@ -157,24 +220,27 @@ __device__ __forceinline__ void lf_sb_body(Pix *tile, uint8_t *lvl, unsigned *th
   if (lane < n && y0 + lane < ph && (lane >> 3) < mrows) {
     const int mr = lane >> 3;
     Pix *row = tile + (8 + lane) * TP;
-    int w[16];
+    int w[16], nxt[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = row[k];
+    for (int k = 0; k < 16; ++k) w[k] = row[k];
+    unsigned cE = vE[mr * ncol], cI = vI[mr * ncol];
     for (int c = 0; c < ncol; ++c) {
+      // prefetch the next position's samples and controls while this one is filtered
+      const int cn = c + 1 < ncol ? c + 1 : c;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) w[8 + k] = row[8 + c * 8 + k];
-      const int bit = mr * ncol + c;
-      const int level = lvl[bit];
-      const int kind = ((l16 >> bit) & 1) ? 16 : ((l8 >> bit) & 1) ? 8 : ((l4 >> bit) & 1) ? 4 : 0;
-      int lv = level;
-      // vpx_lpf_vertical_16_dual applies the even mask row's thresholds to both rows of a pair
-      if (kind == 16 && (mr & 1) && ((l16 >> (bit - ncol)) & 1)) lv = lvl[bit - ncol];
-      filter_window(w, 8, kind, thr3[lv], sh);
-      filter_window(w, 12, ((mint >> bit) & 1) ? 4 : 0, thr3[level], sh);
+      for (int k = 0; k < 8; ++k) nxt[k] = row[8 + cn * 8 + k];
+      const unsigned nE = vE[mr * ncol + cn], nI = vI[mr * ncol + cn];
+      filter_window(w, 8, cE >> 24, cE, sh);
+      filter_window(w, 12, cI >> 24, cI, sh);
 #pragma unroll
       for (int k = 0; k < 8; ++k) row[c * 8 + k] = (Pix)w[k];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) w[k] = w[8 + k];
+      for (int k = 0; k < 8; ++k) {
+        w[k] = w[8 + k];
+        w[8 + k] = nxt[k];
+      }
+      cE = nE;
+      cI = nI;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) row[ncol * 8 + k] = (Pix)w[k];
@@ -184,42 +250,27 @@ __device__ __forceinline__ void lf_sb_body(Pix *tile, uint8_t *lvl, unsigned *th
   // ---- horizontal edges: lane = sample column; the window slides down the column
   if (lane < n && x0 + lane < pw) {
     const int c = lane >> 3;  // mask column
-    int skip_int = -1;        // skip_border_4x4_r (vp9_loopfilter.c:1385-1387)
-    if (pl)
-      for (int r = 0; r < rows_mi; r += 2)
-        if (mi_row + r == mi_rows - 1) skip_int = r >> 1;
     Pix *col = tile + 8 + lane;
-    int w[16];
+    int w[16], nxt[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = col[k * TP];
+    for (int k = 0; k < 16; ++k) w[k] = col[k * TP];
+    unsigned cE = hE[c], cI = hI[c];
     for (int mr = 0; mr < mrows; ++mr) {
+      const int mn = mr + 1 < mrows ? mr + 1 : mr;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) w[8 + k] = col[(8 + mr * 8 + k) * TP];
-      const bool edge_ok = !(mi_row == 0 && mr == 0);
-      const int bit = mr * ncol + c;
-      const int level = lvl[bit];
-      const unsigned rowmask16 = edge_ok ? (unsigned)((a16 >> (mr * ncol)) & ((1u << ncol) - 1)) : 0u;
-      int kind = 0, lv = level;
-      if ((rowmask16 >> c) & 1) {
-        kind = 16;
-        // the second segment of a 16-wide "dual" pair reuses the first's thresholds
-        // (vp9_loopfilter.c:466-469); pairs form from the start of a run of 16-wide segments
-        int run = 0;
-        for (int k = c - 1; k >= 0 && ((rowmask16 >> k) & 1); --k) ++run;
-        if (run & 1) lv = lvl[bit - 1];
-      } else if (edge_ok && ((a8 >> bit) & 1)) {
-        kind = 8;
-      } else if (edge_ok && ((a4 >> bit) & 1)) {
-        kind = 4;
-      }
-      filter_window(w, 8, kind, thr3[lv], sh);
-      // the 16-wide branch of filter_selectively_horiz never filters the interior edge (:465-538)
-      const bool bi = kind != 16 && (mr != skip_int) && ((mint >> bit) & 1);
-      filter_window(w, 12, bi ? 4 : 0, thr3[level], sh);
+      for (int k = 0; k < 8; ++k) nxt[k] = col[(8 + mn * 8 + k) * TP];
+      const unsigned nE = hE[mn * ncol + c], nI = hI[mn * ncol + c];
+      filter_window(w, 8, cE >> 24, cE, sh);
+      filter_window(w, 12, cI >> 24, cI, sh);
 #pragma unroll
       for (int k = 0; k < 8; ++k) col[(mr * 8 + k) * TP] = (Pix)w[k];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) w[k] = w[8 + k];
+      for (int k = 0; k < 8; ++k) {
+        w[k] = w[8 + k];
+        w[8 + k] = nxt[k];
+      }
+      cE = nE;
+      cI = nI;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) col[(mrows * 8 + k) * TP] = (Pix)w[k];
@@ -227,11 +278,12 @@ __device__ __forceinline__ void lf_sb_body(Pix *tile, uint8_t *lvl, unsigned *th
   __syncthreads();
 
   // write the tile back (the top-left 8x8 corner belongs to nobody here)
-  for (int i = lane; i < dpr * tw; i += 64) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = lane + 64 * k;
     const int r = i / dpr, d = i - r * dpr;
-    if (r < 8 && d * PPD < 8) continue;
     const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
-    if (gx >= 0 && gy >= 0 && gx < pw && gy < ph)
+    if (i < total && !(r < 8 && d * PPD < 8) && gx >= 0 && gy >= 0 && gx < pw && gy < ph)
       *(unsigned *)(plane + (size_t)gy * stride + gx) = tile32[r * TPD + d];
   }
 }
@@ -240,15 +292,14 @@ template <typename Pix>
 __global__ __launch_bounds__(64) void lf_diag_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int t,
                                                      int r_min, LfThreshDev th, FrameDev f, int mi_rows) {
   __shared__ __attribute__((aligned(16))) Pix tile[72 * TileCfg<Pix>::TP];
-  __shared__ uint8_t lvl[64];
-  __shared__ unsigned thr3[64];
+  __shared__ unsigned ctl[256];
   const int sr = r_min + blockIdx.x, sc = t - 2 * sr;
   const int pl = blockIdx.y;
   const vp9hip_lfm &m = lfms[sr * sb_cols + sc];
   if (pl == 0)
-    lf_sb_body<Pix, 64>(tile, lvl, thr3, m, sr, sc, pl, th, f, mi_rows);
+    lf_sb_body<Pix, 64>(tile, ctl, m, sr, sc, pl, th, f, mi_rows);
   else
-    lf_sb_body<Pix, 32>(tile, lvl, thr3, m, sr, sc, pl, th, f, mi_rows);
+    lf_sb_body<Pix, 32>(tile, ctl, m, sr, sc, pl, th, f, mi_rows);
 }
 
 }  // namespace

@@ -98,13 +98,14 @@ __global__ __launch_bounds__(256) void idct_add_kernel(const vp9hip_txb *__restr
   if (x >= f.awidth[pl]) return;
   const int rows = min(N, f.aheight[pl] - (int)blk.y);
   Pix *p = dst + (size_t)blk.y * stride + x;
+  // all destination loads are issued before the first store (the compiler cannot prove that
+  // row k+1 does not alias row k and would otherwise serialise N load->store round trips)
+  int d[N];
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (k < rows) {
-      const int d = (int)p[(size_t)k * stride];
-      p[(size_t)k * stride] = (Pix)clip_pix<Pix>(txfm::add32(d, v[k]), maxv);
-    }
-  }
+  for (int k = 0; k < N; ++k) d[k] = (k < rows) ? (int)p[(size_t)k * stride] : 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (k < rows) p[(size_t)k * stride] = (Pix)clip_pix<Pix>(txfm::add32(d[k], v[k]), maxv);
 }
 
 template <int N>
