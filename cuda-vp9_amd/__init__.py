@@ -45,7 +45,8 @@ INTRA_DTYPE = np.dtype([("coeff_off", "<u4"), ("x", "<u2"), ("y", "<u2"), ("plan
 LFM_DTYPE = np.dtype([("left_y", "<u8", (4,)), ("above_y", "<u8", (4,)), ("int_4x4_y", "<u8"),
                       ("left_uv", "<u2", (4,)), ("above_uv", "<u2", (4,)), ("int_4x4_uv", "<u2"),
                       ("lfl_y", "u1", (64,)), ("reserved", "u1", (6,))])
-assert TXB_DTYPE.itemsize == 16 and INTER_DTYPE.itemsize == 32
+ISLAND_DTYPE = np.dtype([("task_start", "<u4"), ("wave_off_start", "<u4"), ("n_waves", "<u4"), ("reserved", "<u4")])
+assert TXB_DTYPE.itemsize == 16 and INTER_DTYPE.itemsize == 32 and ISLAND_DTYPE.itemsize == 16
 assert INTRA_DTYPE.itemsize == 16 and LFM_DTYPE.itemsize == 160
 
 
@@ -213,6 +214,12 @@ class Context:
         self.check(lib().vp9hip_intra_pred_waves(
             self.handle, ctypes.c_void_p(d_tasks.ptr), ws.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
             len(ws) - 1, ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
+            ctypes.byref(frame.desc)))
+
+    def intra_pred_islands(self, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame):
+        self.check(lib().vp9hip_intra_pred_islands(
+            self.handle, ctypes.c_void_p(d_tasks.ptr), ctypes.c_void_p(d_islands.ptr), int(n_islands),
+            ctypes.c_void_p(d_wave_off.ptr), ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
             ctypes.byref(frame.desc)))
 
     def loop_filter_frame(self, d_lfm, sb_rows, sb_cols, thresh, frame, planes=3):

@@ -208,17 +208,16 @@ __device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t,
     if (k < rows) dst[(size_t)k * f.stride[pl]] = (Pix)p[k];
 }
 
+// Up to SLOTS (8) independent transform blocks, one per 32-lane slot.  `active` slots predict (and
+// add the residual of) tasks[index]; every thread of the workgroup must call this (barriers).
 template <typename Pix, bool HBD>
-__global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task *__restrict__ tasks, int first,
-                                                         int count, const int32_t *__restrict__ coeffs, FrameDev f) {
-  __shared__ int edge[SLOTS][ESIZE];
-  __shared__ int tiles[SLOTS][32 * TPITCH];
+__device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 * TPITCH],
+                                            const vp9hip_intra_task *__restrict__ tasks, int index, bool active,
+                                            const int32_t *__restrict__ coeffs, const FrameDev &f) {
   const int slot = threadIdx.x / SLOT, t = threadIdx.x % SLOT;
-  const int ti = blockIdx.x * SLOTS + slot;
-  const bool active = ti < count;
   vp9hip_intra_task tk;
   memset(&tk, 0, sizeof(tk));
-  if (active) tk = tasks[first + ti];
+  if (active) tk = tasks[index];
   const int bs = 4 << tk.tx_size;
   const int pl = tk.plane;
   const bool lossless = tk.tx_type & 0x80;
@@ -289,16 +288,70 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task
     }
   }
   __syncthreads();
-  if (!active) return;
-  switch (tk.tx_size) {
-    case 0: finish_block<4, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
-    case 1: finish_block<8, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
-    case 2: finish_block<16, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
-    default: finish_block<32, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
+  if (active) {
+    switch (tk.tx_size) {
+      case 0: finish_block<4, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
+      case 1: finish_block<8, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
+      case 2: finish_block<16, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
+      default: finish_block<32, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
+    }
+  }
+}
+
+// One launch per dependency wave of the whole frame (deep structures: key frames).
+template <typename Pix, bool HBD>
+__global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task *__restrict__ tasks, int first,
+                                                         int count, const int32_t *__restrict__ coeffs, FrameDev f) {
+  __shared__ int edge[SLOTS][ESIZE];
+  __shared__ int tiles[SLOTS][32 * TPITCH];
+  const int ti = blockIdx.x * SLOTS + threadIdx.x / SLOT;
+  intra_chunk<Pix, HBD>(edge, tiles, tasks, first + ti, ti < count, coeffs, f);
+}
+
+// One workgroup per ISLAND (connected component of the intra dependency graph, e.g. an intra
+// superblock inside an inter frame): it walks the island's waves in order, 8 blocks at a time,
+// with a workgroup barrier between waves — no kernel boundary, no inter-workgroup traffic.
+// __syncthreads() orders the global stores of one wave before the edge loads of the next for
+// the threads of this workgroup (same CU, same L1).
+template <typename Pix, bool HBD>
+__global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_task *__restrict__ tasks,
+                                                           const vp9hip_intra_island *__restrict__ islands,
+                                                           const int32_t *__restrict__ wave_off,
+                                                           const int32_t *__restrict__ coeffs, FrameDev f) {
+  __shared__ int edge[SLOTS][ESIZE];
+  __shared__ int tiles[SLOTS][32 * TPITCH];
+  const vp9hip_intra_island isl = islands[blockIdx.x];
+  const int slot = threadIdx.x / SLOT;
+  for (int w = 0; w < isl.n_waves; ++w) {
+    const int begin = wave_off[isl.wave_off_start + w], end = wave_off[isl.wave_off_start + w + 1];
+    for (int base = begin; base < end; base += SLOTS) {
+      const int ti = base + slot;
+      intra_chunk<Pix, HBD>(edge, tiles, tasks, isl.task_start + ti, ti < end, coeffs, f);
+    }
+    __syncthreads();
   }
 }
 
 }  // namespace
+
+extern "C" int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
+                                         const vp9hip_intra_island *d_islands, int n_islands,
+                                         const int32_t *d_wave_off, const int32_t *d_coeffs,
+                                         const vp9hip_frame *frame) {
+  if (!ctx) return VP9HIP_EINVAL;
+  if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !frame_ok(frame))
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_islands: bad argument");
+  if (n_islands == 0) return VP9HIP_OK;
+  const FrameDev f = to_dev(frame);
+  if (frame->hbd)
+    hipLaunchKernelGGL((intra_island_kernel<uint16_t, true>), dim3(n_islands), dim3(256), 0, ctx->stream, d_tasks,
+                       d_islands, d_wave_off, d_coeffs, f);
+  else
+    hipLaunchKernelGGL((intra_island_kernel<uint8_t, false>), dim3(n_islands), dim3(256), 0, ctx->stream, d_tasks,
+                       d_islands, d_wave_off, d_coeffs, f);
+  VP9HIP_CHECK(ctx, hipGetLastError());
+  return VP9HIP_OK;
+}
 
 extern "C" int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks, const int32_t *wave_start,
                                        int n_waves, const int32_t *d_coeffs, const vp9hip_frame *frame) {

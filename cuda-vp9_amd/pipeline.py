@@ -25,6 +25,11 @@ class FrameJob:
         self.d_txb = ctx.alloc(wl["txb"]) if len(wl["txb"]) else None
         self.d_coeffs = ctx.alloc(wl["coeffs"])
         self.d_intra = ctx.alloc(wl["intra_sorted"]) if len(wl["intra_sorted"]) else None
+        self.d_isl_tasks = ctx.alloc(wl["intra_island_tasks"]) if len(wl["intra_island_tasks"]) else None
+        self.d_islands = ctx.alloc(wl["intra_islands"]) if len(wl["intra_islands"]) else None
+        self.d_isl_woff = ctx.alloc(wl["intra_island_wave_off"])
+        self.d_big_tasks = ctx.alloc(wl["intra_big_tasks"]) if len(wl["intra_big_tasks"]) else None
+        self.use_islands = True
         self.d_lfm = ctx.alloc(wl["lfm"])
         self.th = LfThresh()
         mblim, lim, hev = wl["thresholds"]
@@ -42,7 +47,15 @@ class FrameJob:
         if "txb" in phases and self.d_txb is not None:
             ctx.idct_add_batch(self.d_txb, wl["txb_counts"], self.d_coeffs, self.dst)
         if "intra" in phases and self.d_intra is not None:
-            ctx.intra_pred_waves(self.d_intra, wl["wave_start"], self.d_coeffs, self.dst)
+            if self.use_islands:
+                # islands: one launch; components too large for one workgroup keep per-wave launches
+                if self.d_islands is not None:
+                    ctx.intra_pred_islands(self.d_isl_tasks, self.d_islands, len(wl["intra_islands"]),
+                                           self.d_isl_woff, self.d_coeffs, self.dst)
+                if self.d_big_tasks is not None:
+                    ctx.intra_pred_waves(self.d_big_tasks, wl["intra_big_wave_start"], self.d_coeffs, self.dst)
+            else:
+                ctx.intra_pred_waves(self.d_intra, wl["wave_start"], self.d_coeffs, self.dst)
         if "lf" in phases:
             ctx.loop_filter_frame(self.d_lfm, wl["sb_rows"], wl["sb_cols"], self.th, self.dst, 3)
 
@@ -52,7 +65,8 @@ class FrameJob:
     def free(self):
         for fr in self.refs + [self.dst]:
             fr.free()
-        for b in (self.d_inter, self.d_txb, self.d_coeffs, self.d_intra, self.d_lfm):
+        for b in (self.d_inter, self.d_txb, self.d_coeffs, self.d_intra, self.d_lfm, self.d_isl_tasks, self.d_islands,
+                  self.d_isl_woff, self.d_big_tasks):
             if b is not None:
                 b.free()
 

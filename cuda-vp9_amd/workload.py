@@ -197,11 +197,21 @@ def build_lf_masks(blocks, aw, ah):
     return out, sb_rows, sb_cols
 
 
-def intra_levels(tasks, dims):
+def intra_levels(tasks, dims, want_components=False):
     """Dependency level (1-based) of each intra task, tasks given in decode order.  A block
     depends on the blocks that own its left column, above row (2*bs wide only for 4x4 blocks
-    with have_right) and above-left sample; already-reconstructed inter area is level 0."""
+    with have_right) and above-left sample; already-reconstructed inter area is level 0.
+    With want_components also returns the connected component (island) id of every task."""
     maps = [np.zeros((ah // 4 + 2, aw // 4 + 2), np.int32) for (aw, ah) in dims]
+    owner = [np.full((ah // 4 + 2, aw // 4 + 2), -1, np.int64) for (aw, ah) in dims] if want_components else None
+    parent = list(range(len(tasks)))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
     lv = np.zeros(len(tasks), np.int32)
     px, py, pp = tasks["x"] // 4, tasks["y"] // 4, tasks["plane"]
     nn = 1 << tasks["tx_size"].astype(np.int32)
@@ -212,17 +222,74 @@ def intra_levels(tasks, dims):
         cx, cy, n = int(px[i]), int(py[i]), int(nn[i])
         xmax, ymax = aw // 4, ah // 4
         l = 0
+        deps = []
         if fl[i] & 2:
             l = max(l, int(m[cy:min(cy + n, ymax), cx - 1].max()))
+            if want_components:
+                deps.append(owner[pp[i]][cy:min(cy + n, ymax), cx - 1])
         if fl[i] & 1:
             ext = 2 * n if (n == 1 and (fl[i] & 4)) else n
             l = max(l, int(m[cy - 1, cx:min(cx + ext, xmax)].max()))
+            if want_components:
+                deps.append(owner[pp[i]][cy - 1, cx:min(cx + ext, xmax)])
             if fl[i] & 2:
                 l = max(l, int(m[cy - 1, cx - 1]))
+                if want_components:
+                    deps.append(owner[pp[i]][cy - 1, cx - 1:cx])
         l += 1
         m[cy:cy + n, cx:cx + n] = l
         lv[i] = l
+        if want_components:
+            for d in deps:
+                for o in np.unique(d):
+                    if o >= 0:
+                        ra, rb = find(int(o)), find(i)
+                        if ra != rb:
+                            parent[rb] = ra
+            owner[pp[i]][cy:cy + n, cx:cx + n] = i
+    if want_components:
+        comp = np.array([find(i) for i in range(len(tasks))], np.int64)
+        return lv, comp
     return lv
+
+
+def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
+    """Split the intra tasks into islands (one workgroup each, vp9hip_intra_pred_islands) and a
+    remainder of very large components that keeps the per-wave launches."""
+    from . import ISLAND_DTYPE
+    n = len(tasks)
+    if n == 0:
+        return (tasks, np.zeros(0, ISLAND_DTYPE), np.zeros(1, np.int32), tasks, np.zeros(1, np.int32))
+    ids, inv, counts = np.unique(comp, return_inverse=True, return_counts=True)
+    big = counts[inv] > max_island_tasks
+    # islands: sort by (component, level)
+    idx = np.flatnonzero(~big)
+    order = idx[np.lexsort((levels[idx], inv[idx]))]
+    isl_tasks = tasks[order]
+    islands, wave_off = [], []
+    if len(order):
+        c_sorted, l_sorted = inv[order], levels[order]
+        starts = np.flatnonzero(np.r_[True, c_sorted[1:] != c_sorted[:-1]])
+        ends = np.r_[starts[1:], len(order)]
+        for a, b in zip(starts, ends):
+            lv = l_sorted[a:b]
+            w = np.flatnonzero(np.r_[True, lv[1:] != lv[:-1]])
+            islands.append((a, len(wave_off), len(w), 0))
+            wave_off.extend(w.tolist())
+            wave_off.append(b - a)
+    islands = np.array(islands, dtype=ISLAND_DTYPE) if islands else np.zeros(0, ISLAND_DTYPE)
+    wave_off = np.array(wave_off if wave_off else [0], np.int32)
+    # remainder: global waves
+    idx = np.flatnonzero(big)
+    order = idx[np.argsort(levels[idx], kind="stable")]
+    big_tasks = tasks[order]
+    if len(order):
+        lv = levels[order]
+        nw = int(lv.max())
+        wave_start = np.searchsorted(lv, np.arange(1, nw + 2)).astype(np.int32)
+    else:
+        wave_start = np.zeros(1, np.int32)
+    return isl_tasks, islands, wave_off, big_tasks, wave_start
 
 
 def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_frac=0.35, compound_frac=0.15,
@@ -368,7 +435,8 @@ def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_fr
     have_left = ((T["x"][sel] - pbx) > 0) | (bx[b_of] > 0)
     have_right = (T["x"][sel] - pbx + n_px) < pbs
     itasks["flags"] = have_top.astype(np.uint8) | (have_left.astype(np.uint8) << 1) | (have_right.astype(np.uint8) << 2)
-    levels = intra_levels(itasks, dims)
+    levels, comp = intra_levels(itasks, dims, want_components=True)
+    isl_tasks, islands, isl_wave_off, big_tasks, big_wave_start = pack_intra_islands(itasks, levels, comp)
     lo = np.argsort(levels, kind="stable")
     itasks_sorted = itasks[lo]
     n_waves = int(levels.max()) if len(levels) else 0
@@ -382,5 +450,7 @@ def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_fr
     return dict(width=width, height=height, bd=bd, hbd=hbd, dims=dims, crop=crop, refs=refs, blocks=blocks,
                 inter_tasks=inter_tasks, txb=txb_sorted, txb_counts=txb_counts, coeffs=coeffs,
                 intra_decode_order=itasks, intra_sorted=itasks_sorted, wave_start=wave_start, n_waves=n_waves,
+                intra_island_tasks=isl_tasks, intra_islands=islands, intra_island_wave_off=isl_wave_off,
+                intra_big_tasks=big_tasks, intra_big_wave_start=big_wave_start,
                 lfm=lfm, sb_rows=sb_rows, sb_cols=sb_cols, thresholds=lf_thresholds(sharpness),
                 n_blocks=nb, n_txb=nt)

@@ -175,6 +175,23 @@ int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
                             const int32_t *wave_start /* HOST, n_waves+1 entries */, int n_waves,
                             const int32_t *d_coeffs, const vp9hip_frame *frame);
 
+/* Island form of the same thing, ONE launch: an island is a connected component of the intra
+ * dependency graph (in an inter frame: an isolated intra block or a cluster of them; inter
+ * blocks are already reconstructed and cut the graph).  Records of an island are contiguous in
+ * d_tasks starting at task_start, sorted by wave; d_wave_off[wave_off_start + w] is the offset
+ * (relative to task_start) of its wave w, with one extra end entry.  Islands are independent, one
+ * workgroup walks one island.  Use vp9hip_intra_pred_waves for very large islands (key frames). */
+typedef struct vp9hip_intra_island {
+  uint32_t task_start;
+  uint32_t wave_off_start;
+  uint32_t n_waves;
+  uint32_t reserved;
+} vp9hip_intra_island; /* 16 bytes */
+int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
+                              const vp9hip_intra_island *d_islands, int n_islands,
+                              const int32_t *d_wave_off /* DEVICE */, const int32_t *d_coeffs,
+                              const vp9hip_frame *frame);
+
 /* ------------------------------------------------------------------------------------------
  * (a11–a12) loop filter of a whole frame.  Per 64x64 superblock one vp9hip_lfm record (the
  * content of libvpx's LOOP_FILTER_MASK, vp9_loopfilter.h:60-68, built by vp9_build_mask /
