@@ -116,3 +116,27 @@ def test_intra_waves_match_sequential_oracle(hip, oracle, bd, hbd, resid):
         assert bad.size == 0, f"plane {p}: {len(bad)} px differ, first {bad[:4]} (waves={nw})"
     assert len(tasks) > 200 and nw > 5
     ctx.close()
+
+
+def test_intra_islands_match_sequential_oracle(hip, oracle):
+    """Island form (one launch, one workgroup per connected component) on an inter frame with
+    intra clusters and on an all-intra frame: same pixels as the oracle run in decode order."""
+    import cuda_vp9_amd.pipeline as pipeline
+    import cuda_vp9_amd.workload as workload
+    import frame_check
+    for kw in (dict(intra_frac=0.4), dict(all_intra=True)):
+        wl = workload.make_frame_workload(328, 200, seed=11, **kw)
+        assert len(wl["intra_islands"]) >= 3
+        ctx = hip.Context(0)
+        job = pipeline.FrameJob(ctx, wl)
+        for use_islands in (True, False):
+            job.use_islands = use_islands
+            job.clear_dst()
+            job.run(phases=("inter", "txb", "intra"))
+            ctx.sync()
+            got = job.download()
+            exp, _ = frame_check.oracle_frame(oracle, wl, phases=("inter", "txb", "intra"))
+            for p in range(3):
+                assert np.array_equal(got[p], exp[p]), (kw, use_islands, p)
+        job.free()
+        ctx.close()
