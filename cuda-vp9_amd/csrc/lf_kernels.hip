@@ -18,6 +18,8 @@
 // neighbours it modifies) is staged in LDS.
 //
 // Algorithmic bytes per frame: 2 * P * bps (every sample read and written once) + 160 * #SB.
+#include <stdlib.h>
+
 #include "vp9hip_internal.h"
 
 namespace {
@@ -107,48 +109,16 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
   w[q - 2] = sclamp(ps1 + f, lo, hi) + off;
 }
 
-// One (superblock, plane): N = 64 (luma) or 32 (4:2:0 chroma) samples per side.
-// ctl: 4 x 64 dwords of LDS: per mask bit the packed (kind << 24 | hev << 16 | lim << 8 | mblim)
-// of the block-edge filter and of the interior 4x4 filter, for the vertical and horizontal pass.
-template <typename Pix, int N>
-__device__ __forceinline__ void lf_sb_body(Pix *tile, unsigned *ctl, const vp9hip_lfm &m, int sr, int sc, int pl,
-                                           const LfThreshDev &th, const FrameDev &f, int mi_rows) {
-  constexpr int TP = TileCfg<Pix>::TP;
-  constexpr int PPD = 4 / sizeof(Pix);  // samples per dword
+
+// ---- per-mask-bit filter controls (lane = mask bit) --------------------------------------------
+template <int N>
+__device__ __forceinline__ void lf_controls(unsigned *ctl, const vp9hip_lfm &m, int pl, int mi_row, int rows_mi,
+                                            int mi_rows, const LfThreshDev &th) {
   const int lane = threadIdx.x;
-  const int sh = f.bit_depth - 8;
-  constexpr int n = N;         // samples per superblock side in this plane
-  constexpr int ncol = N / 8;  // mask columns per mask row
+  constexpr int ncol = N / 8;
   constexpr int nbits = ncol * ncol;
-  const int x0 = sc * n, y0 = sr * n;
-  Pix *plane = (Pix *)f.plane[pl];
-  const int stride = f.stride[pl];
-  const int pw = f.awidth[pl], ph = f.aheight[pl];
-  const int mi_row = sr * 8;
-  const int rows_mi = min(8, mi_rows - mi_row);
-  const int mrows = pl ? ((rows_mi + 1) >> 1) : rows_mi;  // mask rows of this plane
   unsigned *vE = ctl, *vI = ctl + 64, *hE = ctl + 128, *hI = ctl + 192;
-
-  // ---- stage the tile: rows y0-8 .. y0+n-1, cols x0-8 .. x0+n-1 (clipped), dword accesses,
-  // all loads issued before the first LDS store
-  constexpr int tw = n + 8;      // samples per tile row
-  constexpr int dpr = tw / PPD;  // dwords per tile row
-  constexpr int total = dpr * tw;
-  constexpr int K = (total + 63) / 64;
-  unsigned *tile32 = (unsigned *)tile;
-  constexpr int TPD = TP / PPD;  // LDS pitch in dwords
-  unsigned stage[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int i = lane + 64 * k;
-    const int r = i / dpr, d = i - r * dpr;
-    const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
-    stage[k] = 0;
-    if (i < total && gx >= 0 && gy >= 0 && gx < pw && gy < ph)
-      stage[k] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
-  }
-
-  // ---- per-mask-bit filter controls (lane = mask bit), vp9_loopfilter.c:297-375, 453-544
+  // vp9_loopfilter.c:297-375, 453-544
   if (lane < nbits) {
     uint64_t l16, l8, l4, a16, a8, a4, mint;
     int level, level_left = 0, level_up = 0;
@@ -208,14 +178,17 @@ __device__ __forceinline__ void lf_sb_body(Pix *tile, unsigned *ctl, const vp9hi
       hI[bit] = (bi ? (4u << 24) : 0u) | thr3(level);
     }
   }
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int i = lane + 64 * k;
-    const int r = i / dpr, d = i - r * dpr;
-    if (i < total) tile32[r * TPD + d] = stage[k];
-  }
-  __syncthreads();
+}
 
+// ---- the two passes over a staged tile ------------------------------------------------------------
+template <typename Pix, int N>
+__device__ __forceinline__ void lf_passes(Pix *tile, const unsigned *ctl, int x0, int y0, int pw, int ph, int mrows,
+                                          int sh) {
+  constexpr int TP = TileCfg<Pix>::TP;
+  constexpr int n = N;
+  constexpr int ncol = N / 8;
+  const int lane = threadIdx.x;
+  const unsigned *vE = ctl, *vI = ctl + 64, *hE = ctl + 128, *hI = ctl + 192;
   // ---- vertical edges: lane = sample row; a 16-sample window slides along the row
   if (lane < n && y0 + lane < ph && (lane >> 3) < mrows) {
     const int mr = lane >> 3;
@@ -277,6 +250,57 @@ __device__ __forceinline__ void lf_sb_body(Pix *tile, unsigned *ctl, const vp9hi
   }
   __syncthreads();
 
+}
+
+// One (superblock, plane): N = 64 (luma) or 32 (4:2:0 chroma) samples per side.
+// ctl: 4 x 64 dwords of LDS: per mask bit the packed (kind << 24 | hev << 16 | lim << 8 | mblim)
+// of the block-edge filter and of the interior 4x4 filter, for the vertical and horizontal pass.
+template <typename Pix, int N>
+__device__ __forceinline__ void lf_sb_body(Pix *tile, unsigned *ctl, const vp9hip_lfm &m, int sr, int sc, int pl,
+                                           const LfThreshDev &th, const FrameDev &f, int mi_rows) {
+  constexpr int TP = TileCfg<Pix>::TP;
+  constexpr int PPD = 4 / sizeof(Pix);  // samples per dword
+  const int lane = threadIdx.x;
+  const int sh = f.bit_depth - 8;
+  constexpr int n = N;         // samples per superblock side in this plane
+  constexpr int ncol = N / 8;  // mask columns per mask row
+  const int x0 = sc * n, y0 = sr * n;
+  Pix *plane = (Pix *)f.plane[pl];
+  const int stride = f.stride[pl];
+  const int pw = f.awidth[pl], ph = f.aheight[pl];
+  const int mi_row = sr * 8;
+  const int rows_mi = min(8, mi_rows - mi_row);
+  const int mrows = pl ? ((rows_mi + 1) >> 1) : rows_mi;  // mask rows of this plane
+  // ---- stage the tile: rows y0-8 .. y0+n-1, cols x0-8 .. x0+n-1 (clipped), dword accesses,
+  // all loads issued before the first LDS store
+  constexpr int tw = n + 8;      // samples per tile row
+  constexpr int dpr = tw / PPD;  // dwords per tile row
+  constexpr int total = dpr * tw;
+  constexpr int K = (total + 63) / 64;
+  unsigned *tile32 = (unsigned *)tile;
+  constexpr int TPD = TP / PPD;  // LDS pitch in dwords
+  unsigned stage[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = lane + 64 * k;
+    const int r = i / dpr, d = i - r * dpr;
+    const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
+    stage[k] = 0;
+    if (i < total && gx >= 0 && gy >= 0 && gx < pw && gy < ph)
+      stage[k] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
+  }
+
+  lf_controls<N>(ctl, m, pl, mi_row, rows_mi, mi_rows, th);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = lane + 64 * k;
+    const int r = i / dpr, d = i - r * dpr;
+    if (i < total) tile32[r * TPD + d] = stage[k];
+  }
+  __syncthreads();
+
+  lf_passes<Pix, N>(tile, ctl, x0, y0, pw, ph, mrows, sh);
+
   // write the tile back (the top-left 8x8 corner belongs to nobody here)
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -302,6 +326,154 @@ __global__ __launch_bounds__(64) void lf_diag_kernel(const vp9hip_lfm *__restric
     lf_sb_body<Pix, 32>(tile, ctl, m, sr, sc, pl, th, f, mi_rows);
 }
 
+
+// =============================================================================================
+// Row-walking form: ONE launch.  Workgroup (r, plane) owns superblock row r and walks it left to
+// right, which is the order the vertical-edge chain imposes anyway; it may start superblock c
+// once row r-1 has finished superblock c+1 (the (r-1,c+1) dependency above).  Rows publish their
+// progress through a counter per (plane, row); the only pixels that cross workgroups are the
+// bottom 8 rows of a superblock row, which row r+1 reads as its "rows above".
+//
+// Hand-off protocol (MI355X_MICROARCH.md "Valid forms", cdna_hip_programming.md Guideline 16, R1
+// with a counter): the handed-off rows are stored write-through (agent-scope relaxed atomic
+// stores = global_store sc1), the single storing wave drains (s_waitcnt vmcnt(0)), then one lane
+// stores the counter with an agent-scope atomic; the consumer polls the counter with agent-scope
+// relaxed loads (s_sleep back-off, BOUNDED spin) and reads the rows with agent-scope relaxed
+// loads (sc1) only after the poll matched.  Everything else a workgroup touches is private to it
+// for the duration of the launch (plain loads/stores).  All sb_rows x planes workgroups are
+// co-resident (69 at 1440p), and row r only ever waits on row r-1, so there is no cycle.
+// The left 8 columns of a tile never leave LDS between two superblocks of a row.
+constexpr int LF_SPIN_LIMIT = 1 << 18;  // x (s_sleep + L2 round trip) ~ a fraction of a second, then give up
+
+__device__ __forceinline__ unsigned ld_sc1(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(unsigned *p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename Pix, int N>
+__device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9hip_lfm *__restrict__ lfms, int sb_cols,
+                                            int sr, int pl, const LfThreshDev &th, const FrameDev &f, int mi_rows,
+                                            int *progress_prev, int *progress_mine, int *err) {
+  constexpr int TP = TileCfg<Pix>::TP;
+  constexpr int PPD = 4 / sizeof(Pix);
+  constexpr int n = N;
+  constexpr int TPD = TP / PPD;
+  constexpr int DPR = n / PPD;                 // dwords per interior row
+  constexpr int KI = (n * DPR + 63) / 64;      // interior dwords per lane
+  constexpr int KA = (8 * DPR + 63) / 64;      // above-row dwords per lane
+  const int lane = threadIdx.x;
+  const int sh = f.bit_depth - 8;
+  Pix *plane = (Pix *)f.plane[pl];
+  const int stride = f.stride[pl];
+  const int pw = f.awidth[pl], ph = f.aheight[pl];
+  const int y0 = sr * n;
+  const int mi_row = sr * 8;
+  const int rows_mi = min(8, mi_rows - mi_row);
+  const int mrows = pl ? ((rows_mi + 1) >> 1) : rows_mi;
+  unsigned *tile32 = (unsigned *)tile;
+
+  bool dead = false;  // a wait timed out: stop waiting (the error flag is set), just finish
+  for (int sc = 0; sc < sb_cols; ++sc) {
+    const int x0 = sc * n;
+    // interior of this superblock: rows y0.., cols x0..  (private to this workgroup: plain loads)
+    unsigned reg[KI];
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int i = lane + 64 * k;
+      const int r = i / DPR, d = i - r * DPR;
+      const int gx = x0 + d * PPD, gy = y0 + r;
+      reg[k] = 0;
+      if (i < n * DPR && gx < pw && gy < ph) reg[k] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
+    }
+    lf_controls<N>(ctl, lfms[sr * sb_cols + sc], pl, mi_row, rows_mi, mi_rows, th);
+    // rows above: produced by row sr-1, handed off through its progress counter
+    unsigned above[KA];
+#pragma unroll
+    for (int k = 0; k < KA; ++k) above[k] = 0;
+    if (sr > 0) {
+      const int need = min(sc + 2, sb_cols);
+      int spins = 0;
+      while (!dead && __hip_atomic_load(progress_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > LF_SPIN_LIMIT) {
+          if (lane == 0) atomicExch(err, 1);
+          dead = true;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int k = 0; k < KA; ++k) {
+        const int i = lane + 64 * k;
+        const int r = i / DPR, d = i - r * DPR;
+        const int gx = x0 + d * PPD, gy = y0 - 8 + r;
+        if (i < 8 * DPR && gx < pw) above[k] = ld_sc1((const unsigned *)(plane + (size_t)gy * stride + gx));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int i = lane + 64 * k;
+      const int r = i / DPR, d = i - r * DPR;
+      if (i < n * DPR) tile32[(8 + r) * TPD + 8 / PPD + d] = reg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+      const int i = lane + 64 * k;
+      const int r = i / DPR, d = i - r * DPR;
+      if (i < 8 * DPR) tile32[r * TPD + 8 / PPD + d] = above[k];
+    }
+    __syncthreads();
+    lf_passes<Pix, N>(tile, ctl, x0, y0, pw, ph, mrows, sh);
+    // ---- write back.  Final now: tile columns [0, n) (+ the right strip for the last superblock
+    // of the row), rows above included.  The bottom 8 rows go out write-through (handed to row sr+1).
+    const bool last = (sc == sb_cols - 1) || (x0 + n >= pw);
+    const int wcols = last ? n + 8 : n;  // tile columns of the superblock rows that are final now
+    constexpr int wd = (n + 8) / PPD;
+    for (int i = lane; i < (n + 8) * wd; i += 64) {
+      const int r = i / wd, d = i - r * wd;
+      const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
+      // rows above: this superblock's own columns (tile columns 8 .. n+7); superblock rows: tile
+      // columns 0 .. wcols-1 (the right strip stays in LDS for the next superblock)
+      if (r < 8 ? (d * PPD < 8) : (d * PPD >= wcols)) continue;
+      if (gx < 0 || gy < 0 || gx >= pw || gy >= ph) continue;
+      unsigned *gp = (unsigned *)(plane + (size_t)gy * stride + gx);
+      const unsigned v = tile32[r * TPD + d];
+      // Rows shared with another workgroup go out write-through and are never left dirty in this
+      // XCD's L2: the bottom 8 rows (handed to row sr+1) and the rows above (their 128-byte lines
+      // are still being completed by row sr-1, two superblocks ahead).
+      if (r >= n || r < 8)
+        st_sc1(gp, v);
+      else
+        *gp = v;
+    }
+    // slide: the right 8 columns become the left strip of the next superblock
+    if (!last && lane < n) {
+#pragma unroll
+      for (int d = 0; d < 8 / PPD; ++d) tile32[(8 + lane) * TPD + d] = tile32[(8 + lane) * TPD + n / PPD + d];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(progress_mine, last ? sb_cols : sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) break;
+  }
+}
+
+template <typename Pix>
+__global__ __launch_bounds__(64) void lf_rows_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
+                                                     LfThreshDev th, FrameDev f, int mi_rows, int *progress,
+                                                     int *err) {
+  __shared__ __attribute__((aligned(16))) Pix tile[72 * TileCfg<Pix>::TP];
+  __shared__ unsigned ctl[256];
+  const int sr = blockIdx.x, pl = blockIdx.y;
+  int *prev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
+  int *mine = progress + pl * sb_rows + sr;
+  if (pl == 0)
+    lf_row_body<Pix, 64>(tile, ctl, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
+  else
+    lf_row_body<Pix, 32>(tile, ctl, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
+}
+
 }  // namespace
 
 extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
@@ -318,6 +490,28 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
   memcpy(&th, h_thresh, sizeof(th));
   const FrameDev f = to_dev(frame);
   const int mi_rows = frame->aheight[0] / 8;
+  static int use_diag = -1;
+  if (use_diag < 0) {
+    const char *e = getenv("VP9HIP_LF_DIAG");
+    use_diag = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (!use_diag) {
+    // one launch: a workgroup per (superblock row, plane), progress counters in context scratch
+    const size_t need = (size_t)(3 * sb_rows + 1) * sizeof(int);
+    int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
+    if (rc) return rc;
+    int *progress = (int *)ctx->scratch, *err = progress + 3 * sb_rows;
+    VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
+    ctx->lf_err_flag = err;
+    if (frame->hbd)
+      hipLaunchKernelGGL(lf_rows_kernel<uint16_t>, dim3(sb_rows, planes), dim3(64), 0, ctx->stream, d_lfm, sb_cols,
+                         sb_rows, th, f, mi_rows, progress, err);
+    else
+      hipLaunchKernelGGL(lf_rows_kernel<uint8_t>, dim3(sb_rows, planes), dim3(64), 0, ctx->stream, d_lfm, sb_cols,
+                         sb_rows, th, f, mi_rows, progress, err);
+    VP9HIP_CHECK(ctx, hipGetLastError());
+    return VP9HIP_OK;
+  }
   const int t_max = (sb_cols - 1) + 2 * (sb_rows - 1);
   for (int t = 0; t <= t_max; ++t) {
     // superblock rows r with 0 <= t - 2r < sb_cols

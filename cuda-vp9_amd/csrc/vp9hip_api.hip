@@ -61,6 +61,12 @@ extern "C" void *vp9hip_stream(vp9hip_ctx *ctx) { return ctx ? (void *)ctx->stre
 extern "C" int vp9hip_sync(vp9hip_ctx *ctx) {
   if (!ctx) return VP9HIP_EINVAL;
   VP9HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->lf_err_flag) {
+    int flag = 0;
+    VP9HIP_CHECK(ctx, hipMemcpy(&flag, ctx->lf_err_flag, sizeof(flag), hipMemcpyDeviceToHost));
+    ctx->lf_err_flag = NULL;
+    if (flag) VP9HIP_FAIL(ctx, VP9HIP_EDEVICE, "loop filter: a superblock row timed out waiting for the row above");
+  }
   return VP9HIP_OK;
 }
 

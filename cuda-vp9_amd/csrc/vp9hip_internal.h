@@ -17,6 +17,7 @@ struct vp9hip_ctx {
   void *scratch;
   size_t scratch_bytes;
   int cu_count;
+  int *lf_err_flag;  // device flag: loop-filter wavefront spin timed out (checked by vp9hip_sync)
   void *d_taps;  // packed i8 convolve taps (inter fast path)
   hipEvent_t *ev_begin, *ev_end;  // VP9HIP_TIMER_SLOTS each, created lazily
 };

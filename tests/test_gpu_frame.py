@@ -38,3 +38,23 @@ def test_frame_pipeline_matches_oracle(hip, oracle, W, H, bd, kw):
     assert all(np.array_equal(a, b) for a, b in zip(got, again))
     job.free()
     ctx.close()
+
+
+def test_loop_filter_handoff_is_stable_under_repetition(hip, oracle):
+    """The row-walking loop filter hands pixels between workgroups inside one launch; a stale
+    read would show up as a run-to-run difference.  40 repetitions on a 1440p frame, each compared
+    with the (deterministic) oracle result."""
+    import cuda_vp9_amd.workload as workload
+    import cuda_vp9_amd.pipeline as pipeline
+    wl = workload.make_frame_workload(2560, 1440, seed=99)
+    ctx = hip.Context(0)
+    job = pipeline.FrameJob(ctx, wl)
+    expect, _ = frame_check.oracle_frame(oracle, wl)
+    want = frame_check.frame_md5(expect, wl)
+    for it in range(40):
+        job.run()
+        ctx.sync()
+        got = job.download()
+        assert frame_check.frame_md5(got, wl) == want, f"iteration {it}"
+    job.free()
+    ctx.close()
