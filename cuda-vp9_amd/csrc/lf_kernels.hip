@@ -114,7 +114,7 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
 template <int N>
 __device__ __forceinline__ void lf_controls(unsigned *ctl, const vp9hip_lfm &m, int pl, int mi_row, int rows_mi,
                                             int mi_rows, const LfThreshDev &th) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   constexpr int ncol = N / 8;
   constexpr int nbits = ncol * ncol;
   unsigned *vE = ctl, *vI = ctl + 64, *hE = ctl + 128, *hI = ctl + 192;
@@ -181,13 +181,23 @@ __device__ __forceinline__ void lf_controls(unsigned *ctl, const vp9hip_lfm &m, 
 }
 
 // ---- the two passes over a staged tile ------------------------------------------------------------
-template <typename Pix, int N>
+// WG_SYNC: the tile is shared by the whole workgroup (barriers) or owned by ONE wave (then LDS is
+// in-order for that wave and a fence that drains lgkmcnt and pins the compiler is enough).
+template <bool WG_SYNC>
+__device__ __forceinline__ void lf_tile_sync() {
+  if constexpr (WG_SYNC)
+    __syncthreads();
+  else
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+template <typename Pix, int N, bool WG_SYNC = true>
 __device__ __forceinline__ void lf_passes(Pix *tile, const unsigned *ctl, int x0, int y0, int pw, int ph, int mrows,
                                           int sh) {
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int n = N;
   constexpr int ncol = N / 8;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const unsigned *vE = ctl, *vI = ctl + 64, *hE = ctl + 128, *hI = ctl + 192;
   // ---- vertical edges: lane = sample row; a 16-sample window slides along the row
   if (lane < n && y0 + lane < ph && (lane >> 3) < mrows) {
@@ -218,7 +228,7 @@ __device__ __forceinline__ void lf_passes(Pix *tile, const unsigned *ctl, int x0
 #pragma unroll
     for (int k = 0; k < 8; ++k) row[ncol * 8 + k] = (Pix)w[k];
   }
-  __syncthreads();
+  lf_tile_sync<WG_SYNC>();
 
   // ---- horizontal edges: lane = sample column; the window slides down the column
   if (lane < n && x0 + lane < pw) {
@@ -248,7 +258,7 @@ __device__ __forceinline__ void lf_passes(Pix *tile, const unsigned *ctl, int x0
 #pragma unroll
     for (int k = 0; k < 8; ++k) col[(mrows * 8 + k) * TP] = (Pix)w[k];
   }
-  __syncthreads();
+  lf_tile_sync<WG_SYNC>();
 
 }
 
@@ -459,6 +469,169 @@ __device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9h
   }
 }
 
+
+// Two-wave form of the row walk: wave 0 filters superblock c while wave 1 writes back superblock
+// c-1, prefetches superblock c+1 (interior, mask record, rows above after the progress wait) into
+// the other tile buffer.  Wave 0 itself stores the 8 hand-off rows and publishes the progress as
+// soon as its passes are done, so the row below is not delayed by the pipelining.
+template <typename Pix, int N>
+__device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const vp9hip_lfm *__restrict__ lfms,
+                                             int sb_cols, int sr, int pl, const LfThreshDev &th, const FrameDev &f,
+                                             int mi_rows, int *progress_prev, int *progress_mine, int *err) {
+  constexpr int TP = TileCfg<Pix>::TP;
+  constexpr int PPD = 4 / sizeof(Pix);
+  constexpr int n = N;
+  constexpr int TPD = TP / PPD;
+  constexpr int DPR = n / PPD;
+  constexpr int KI = (n * DPR + 63) / 64;
+  constexpr int KA = (8 * DPR + 63) / 64;
+  constexpr int TILE = 72 * TP;  // samples per tile buffer
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sh = f.bit_depth - 8;
+  Pix *plane = (Pix *)f.plane[pl];
+  const int stride = f.stride[pl];
+  const int pw = f.awidth[pl], ph = f.aheight[pl];
+  const int y0 = sr * n;
+  const int mi_row = sr * 8;
+  const int rows_mi = min(8, mi_rows - mi_row);
+  const int mrows = pl ? ((rows_mi + 1) >> 1) : rows_mi;
+  const int ncols = min(sb_cols, (pw + n - 1) / n);  // superblocks of this plane row
+  bool dead = false;
+
+  // what wave 1 carries from phase 1 (global loads) to phase 2 (LDS stores)
+  unsigned reg[KI], above[KA];
+
+  auto load_sb = [&](int sc) {  // wave 1: global -> registers (waits for the row above)
+    const int x0 = sc * n;
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int i = lane + 64 * k;
+      const int r = i / DPR, d = i - r * DPR;
+      const int gx = x0 + d * PPD, gy = y0 + r;
+      reg[k] = 0;
+      if (i < n * DPR && gx < pw && gy < ph) reg[k] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
+    }
+#pragma unroll
+    for (int k = 0; k < KA; ++k) above[k] = 0;
+    if (sr > 0) {
+      const int need = min(sc + 2, sb_cols);
+      int spins = 0;
+      while (!dead && __hip_atomic_load(progress_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > LF_SPIN_LIMIT) {
+          if (lane == 0) atomicExch(err, 1);
+          dead = true;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int k = 0; k < KA; ++k) {
+        const int i = lane + 64 * k;
+        const int r = i / DPR, d = i - r * DPR;
+        const int gx = x0 + d * PPD, gy = y0 - 8 + r;
+        if (i < 8 * DPR && gx < pw) above[k] = ld_sc1((const unsigned *)(plane + (size_t)gy * stride + gx));
+      }
+    }
+  };
+  auto store_sb = [&](int sc) {  // wave 1: registers -> LDS tile + controls of superblock sc
+    unsigned *t32 = (unsigned *)(tiles + (sc & 1) * TILE);
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int i = lane + 64 * k;
+      const int r = i / DPR, d = i - r * DPR;
+      if (i < n * DPR) t32[(8 + r) * TPD + 8 / PPD + d] = reg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+      const int i = lane + 64 * k;
+      const int r = i / DPR, d = i - r * DPR;
+      if (i < 8 * DPR) t32[r * TPD + 8 / PPD + d] = above[k];
+    }
+    lf_controls<N>(ctls + (sc & 1) * 256, lfms[sr * sb_cols + sc], pl, mi_row, rows_mi, mi_rows, th);
+  };
+  auto bulk_writeback = [&](int sc) {  // wave 1: everything of superblock sc except the hand-off rows
+    const int x0 = sc * n;
+    const unsigned *t32 = (const unsigned *)(tiles + (sc & 1) * TILE);
+    const bool last = sc == ncols - 1;
+    const int wcols = last ? n + 8 : n;
+    constexpr int wd = (n + 8) / PPD;
+    for (int i = lane; i < n * wd; i += 64) {  // tile rows 0 .. n-1
+      const int r = i / wd, d = i - r * wd;
+      const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
+      if (r < 8 ? (d * PPD < 8) : (d * PPD >= wcols)) continue;
+      if (gx < 0 || gy < 0 || gx >= pw || gy >= ph) continue;
+      unsigned *gp = (unsigned *)(plane + (size_t)gy * stride + gx);
+      if (r < 8)
+        st_sc1(gp, t32[r * TPD + d]);  // rows above: lines shared with row sr-1 (see lf_row_body)
+      else
+        *gp = t32[r * TPD + d];
+    }
+  };
+
+  // prologue: superblock 0 into buffer 0
+  if (wave == 1) {
+    load_sb(0);
+    store_sb(0);
+  }
+  __syncthreads();
+  for (int sc = 0; sc < ncols; ++sc) {
+    const int x0 = sc * n;
+    const bool last = sc == ncols - 1;
+    Pix *tile = tiles + (sc & 1) * TILE;
+    // ---- phase 1
+    if (wave == 0) {
+      lf_passes<Pix, N, false>(tile, ctls + (sc & 1) * 256, x0, y0, pw, ph, mrows, sh);
+      // hand-off rows (tile rows n .. n+7) out write-through, then publish: done before the
+      // workgroup barrier so that the row below never waits on this row's prefetch wave
+      unsigned *t32 = (unsigned *)tile;
+      const int wcols = last ? n + 8 : n;
+      constexpr int wd = (n + 8) / PPD;
+      for (int i = lane; i < 8 * wd; i += 64) {
+        const int r = n + i / wd, d = i % wd;
+        const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
+        if (d * PPD >= wcols || gx < 0 || gx >= pw || gy >= ph) continue;
+        st_sc1((unsigned *)(plane + (size_t)gy * stride + gx), t32[r * TPD + d]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_store(progress_mine, last ? sb_cols : sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (sc > 0) bulk_writeback(sc - 1);
+      if (!last) load_sb(sc + 1);
+    }
+    __syncthreads();
+    // ---- phase 2
+    if (wave == 0) {
+      // the right strip becomes the left strip of the next superblock (other buffer)
+      if (!last && lane < n) {
+        const unsigned *t32 = (const unsigned *)tile;
+        unsigned *nt32 = (unsigned *)(tiles + ((sc + 1) & 1) * TILE);
+#pragma unroll
+        for (int d = 0; d < 8 / PPD; ++d) nt32[(8 + lane) * TPD + d] = t32[(8 + lane) * TPD + n / PPD + d];
+      }
+    } else {
+      if (!last) store_sb(sc + 1);
+    }
+    __syncthreads();
+  }
+  if (wave == 1) bulk_writeback(ncols - 1);
+}
+
+template <typename Pix>
+__global__ __launch_bounds__(128) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
+                                                       LfThreshDev th, FrameDev f, int mi_rows, int *progress,
+                                                       int *err) {
+  __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
+  __shared__ unsigned ctls[2 * 256];
+  const int sr = blockIdx.x, pl = blockIdx.y;
+  int *prev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
+  int *mine = progress + pl * sb_rows + sr;
+  if (pl == 0)
+    lf_row2_body<Pix, 64>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
+  else
+    lf_row2_body<Pix, 32>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
+}
+
 template <typename Pix>
 __global__ __launch_bounds__(64) void lf_rows_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                                      LfThreshDev th, FrameDev f, int mi_rows, int *progress,
@@ -490,12 +663,12 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
   memcpy(&th, h_thresh, sizeof(th));
   const FrameDev f = to_dev(frame);
   const int mi_rows = frame->aheight[0] / 8;
-  static int use_diag = -1;
-  if (use_diag < 0) {
-    const char *e = getenv("VP9HIP_LF_DIAG");
-    use_diag = (e && e[0] == '1') ? 1 : 0;
+  static int mode = -1;  // 0: one launch per anti-diagonal, 1: row walk (1 wave), 2: row walk (2 waves)
+  if (mode < 0) {
+    const char *e = getenv("VP9HIP_LF_MODE");
+    mode = (e && !strcmp(e, "diag")) ? 0 : (e && !strcmp(e, "rows")) ? 1 : 2;
   }
-  if (!use_diag) {
+  if (mode != 0) {
     // one launch: a workgroup per (superblock row, plane), progress counters in context scratch
     const size_t need = (size_t)(3 * sb_rows + 1) * sizeof(int);
     int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
@@ -503,7 +676,14 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
     int *progress = (int *)ctx->scratch, *err = progress + 3 * sb_rows;
     VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
     ctx->lf_err_flag = err;
-    if (frame->hbd)
+    if (mode == 2) {
+      if (frame->hbd)
+        hipLaunchKernelGGL(lf_rows2_kernel<uint16_t>, dim3(sb_rows, planes), dim3(128), 0, ctx->stream, d_lfm, sb_cols,
+                           sb_rows, th, f, mi_rows, progress, err);
+      else
+        hipLaunchKernelGGL(lf_rows2_kernel<uint8_t>, dim3(sb_rows, planes), dim3(128), 0, ctx->stream, d_lfm, sb_cols,
+                           sb_rows, th, f, mi_rows, progress, err);
+    } else if (frame->hbd)
       hipLaunchKernelGGL(lf_rows_kernel<uint16_t>, dim3(sb_rows, planes), dim3(64), 0, ctx->stream, d_lfm, sb_cols,
                          sb_rows, th, f, mi_rows, progress, err);
     else
