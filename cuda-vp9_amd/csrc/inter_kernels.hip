@@ -355,6 +355,7 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
                                        const int32_t class_count[6], const vp9hip_frame *refs, int n_refs,
                                        const vp9hip_frame *dst) {
   if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the caller's thread may be on another device
   if (!d_tasks || !class_count || !refs || n_refs <= 0 || n_refs > VP9HIP_MAX_REFS || !frame_ok(dst))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_inter_pred_batch: bad argument");
   RefSet rs;

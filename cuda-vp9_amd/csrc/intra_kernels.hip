@@ -339,6 +339,7 @@ extern "C" int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_tas
                                          const int32_t *d_wave_off, const int32_t *d_coeffs,
                                          const vp9hip_frame *frame) {
   if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the caller's thread may be on another device
   if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !frame_ok(frame))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_islands: bad argument");
   if (n_islands == 0) return VP9HIP_OK;
@@ -356,6 +357,7 @@ extern "C" int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_tas
 extern "C" int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks, const int32_t *wave_start,
                                        int n_waves, const int32_t *d_coeffs, const vp9hip_frame *frame) {
   if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the caller's thread may be on another device
   if (!d_tasks || !wave_start || n_waves < 0 || !frame_ok(frame))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_waves: bad argument");
   const FrameDev f = to_dev(frame);

@@ -127,6 +127,7 @@ int launch_size(vp9hip_ctx *ctx, const vp9hip_txb *blocks, int n, const int32_t 
 extern "C" int vp9hip_idct_add_batch(vp9hip_ctx *ctx, const vp9hip_txb *d_blocks, const int32_t size_count[4],
                                      const int32_t *d_coeffs, const vp9hip_frame *frame) {
   if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the caller's thread may be on another device
   if (!d_blocks || !size_count || !d_coeffs || !frame_ok(frame))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_idct_add_batch: bad argument");
   for (int i = 0; i < 4; ++i)
