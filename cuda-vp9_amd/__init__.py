@@ -50,6 +50,41 @@ assert TXB_DTYPE.itemsize == 16 and INTER_DTYPE.itemsize == 32 and ISLAND_DTYPE.
 assert INTRA_DTYPE.itemsize == 16 and LFM_DTYPE.itemsize == 160
 
 
+# ---- host packers (include/vp9hip_pack.h) ---------------------------------------------------
+BLOCK_DTYPE = np.dtype([("mi_row", "<i2"), ("mi_col", "<i2"), ("sb_type", "u1"), ("tx_size", "u1"), ("skip", "u1"),
+                        ("interp_filter", "u1"), ("ref_frame", "i1", (2,)), ("mode", "u1"), ("uv_mode", "u1"),
+                        ("sub_mode", "u1", (4,)), ("filter_level", "u1"), ("reserved", "u1", (3,)),
+                        ("mv", "<i2", (2, 2)), ("sub_mv", "<i2", (4, 2, 2)), ("reserved2", "u1", (4,))])
+assert BLOCK_DTYPE.itemsize == 64
+
+
+class FrameParams(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ss_x", ctypes.c_int32),
+                ("ss_y", ctypes.c_int32), ("bit_depth", ctypes.c_int32), ("hbd", ctypes.c_int32),
+                ("lossless", ctypes.c_int32), ("log2_tile_cols", ctypes.c_int32),
+                ("ref_width", ctypes.c_int32 * 3), ("ref_height", ctypes.c_int32 * 3),
+                ("build_lf_masks", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+
+
+class CoeffLayout(ctypes.Structure):
+    _fields_ = [("eob", ctypes.c_void_p * 3), ("eob_stride", ctypes.c_int32 * 3)]
+
+
+class Packed(ctypes.Structure):
+    _fields_ = [("inter", ctypes.c_void_p), ("n_inter", ctypes.c_int32), ("inter_class_count", ctypes.c_int32 * 6),
+                ("txb", ctypes.c_void_p), ("n_txb", ctypes.c_int32), ("txb_size_count", ctypes.c_int32 * 4),
+                ("intra_island_tasks", ctypes.c_void_p), ("n_intra_island_tasks", ctypes.c_int32),
+                ("islands", ctypes.c_void_p), ("n_islands", ctypes.c_int32),
+                ("island_wave_off", ctypes.c_void_p), ("n_island_wave_off", ctypes.c_int32),
+                ("intra_big_tasks", ctypes.c_void_p), ("n_intra_big_tasks", ctypes.c_int32),
+                ("big_wave_start", ctypes.c_void_p), ("n_big_waves", ctypes.c_int32),
+                ("intra_decode_order", ctypes.c_void_p), ("n_intra", ctypes.c_int32),
+                ("n_intra_waves", ctypes.c_int32),
+                ("coeff_base", ctypes.c_int64 * 3), ("coeff_count", ctypes.c_int64 * 3), ("coeff_total", ctypes.c_int64),
+                ("lfm", ctypes.c_void_p), ("sb_rows", ctypes.c_int32), ("sb_cols", ctypes.c_int32),
+                ("refs_used", ctypes.c_uint32)]
+
+
 class LfThresh(ctypes.Structure):
     _fields_ = [("mblim", ctypes.c_uint8 * 64), ("lim", ctypes.c_uint8 * 64),
                 ("hev_thr", ctypes.c_uint8 * 64)]
@@ -83,8 +118,69 @@ def lib():
         L.vp9hip_timer_begin.argtypes = [vp, ctypes.c_int]
         L.vp9hip_timer_end.argtypes = [vp, ctypes.c_int]
         L.vp9hip_timer_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        L.vp9hip_packer_create.argtypes = [ctypes.POINTER(vp)]
+        L.vp9hip_packer_destroy.argtypes = [vp]
+        L.vp9hip_packer_destroy.restype = None
+        L.vp9hip_packer_error.argtypes = [vp]
+        L.vp9hip_packer_error.restype = ctypes.c_char_p
+        L.vp9hip_pack_frame.argtypes = [vp, ctypes.POINTER(FrameParams), vp, ctypes.c_int,
+                                        ctypes.POINTER(CoeffLayout), ctypes.POINTER(Packed)]
         _lib = L
     return _lib
+
+
+def _arr(ptr, n, dtype):
+    """Copy n records of dtype out of packer-owned memory."""
+    if not ptr or n <= 0:
+        return np.zeros(0, dtype)
+    buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class Packer:
+    """vp9hip_packer: decoded blocks -> work lists (host C, cuda-vp9_amd/csrc/vp9hip_pack.c)."""
+
+    def __init__(self):
+        self.handle = ctypes.c_void_p()
+        if lib().vp9hip_packer_create(ctypes.byref(self.handle)) != 0:
+            raise Vp9HipError("vp9hip_packer_create failed")
+
+    def pack(self, params: FrameParams, blocks, eob_planes=None):
+        """blocks: BLOCK_DTYPE array in decode order; eob_planes: three int32 2-D arrays indexed [y, x]
+        (the reference's plane_eob layout) or None.  Returns a dict of numpy copies of the lists."""
+        blocks = np.ascontiguousarray(blocks, BLOCK_DTYPE)
+        cl = None
+        keep = []
+        if eob_planes is not None:
+            cl = CoeffLayout()
+            for p in range(3):
+                a = np.ascontiguousarray(eob_planes[p], np.int32)
+                keep.append(a)
+                cl.eob[p] = a.ctypes.data
+                cl.eob_stride[p] = a.shape[1]
+        out = Packed()
+        rc = lib().vp9hip_pack_frame(self.handle, ctypes.byref(params), blocks.ctypes.data, len(blocks),
+                                     ctypes.byref(cl) if cl is not None else None, ctypes.byref(out))
+        if rc != 0:
+            raise Vp9HipError(f"vp9hip_pack_frame failed ({rc}): {lib().vp9hip_packer_error(self.handle).decode()}")
+        n_sb = out.sb_rows * out.sb_cols
+        return dict(
+            inter_tasks=_arr(out.inter, out.n_inter, INTER_DTYPE), inter_class_count=list(out.inter_class_count),
+            txb=_arr(out.txb, out.n_txb, TXB_DTYPE), txb_counts=list(out.txb_size_count),
+            intra_island_tasks=_arr(out.intra_island_tasks, out.n_intra_island_tasks, INTRA_DTYPE),
+            intra_islands=_arr(out.islands, out.n_islands, ISLAND_DTYPE),
+            intra_island_wave_off=_arr(out.island_wave_off, out.n_island_wave_off, np.int32),
+            intra_big_tasks=_arr(out.intra_big_tasks, out.n_intra_big_tasks, INTRA_DTYPE),
+            intra_big_wave_start=_arr(out.big_wave_start, out.n_big_waves + 1, np.int32),
+            intra_decode_order=_arr(out.intra_decode_order, out.n_intra, INTRA_DTYPE),
+            n_waves=out.n_intra_waves, coeff_base=list(out.coeff_base), coeff_count=list(out.coeff_count),
+            coeff_total=out.coeff_total, lfm=_arr(out.lfm, n_sb if out.lfm else 0, LFM_DTYPE),
+            sb_rows=out.sb_rows, sb_cols=out.sb_cols, refs_used=out.refs_used)
+
+    def close(self):
+        if self.handle:
+            lib().vp9hip_packer_destroy(self.handle)
+            self.handle = None
 
 
 class DevBuf:

@@ -1,0 +1,745 @@
+/*
+ * vp9hip_pack.c — host packers (plain C99, no HIP): decoded mode information -> work lists.
+ * See include/vp9hip_pack.h for the list of reference functions each part restates; file:line
+ * citations below are relative to /root/reference/libvpx/.
+ */
+#include "vp9hip_pack.h"
+
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- block geometry (vp9/common/vp9_common_data.c: num_4x4_blocks_{wide,high}_lookup) ------- */
+static const uint8_t kW4[13] = { 1, 1, 2, 2, 2, 4, 4, 4, 8, 8, 8, 16, 16 };
+static const uint8_t kH4[13] = { 1, 2, 1, 2, 4, 2, 4, 8, 4, 8, 16, 8, 16 };
+/* intra_mode_to_tx_type_lookup (vp9/common/vp9_reconintra.c:24-35): DC V H D45 D135 D117 D153 D207 D63 TM */
+static const uint8_t kModeToTxType[10] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3 };
+
+#define MAX_ISLAND_TASKS 4096
+
+typedef struct {
+  void *p;
+  size_t cap; /* bytes */
+} vec;
+
+struct vp9hip_packer {
+  char err[256];
+  vec inter, inter_sorted, txb, txb_sorted, intra, intra_isl, intra_big, islands, wave_off, big_wave_start;
+  vec level, parent, comp_id, comp_size, order_a, order_b, count;
+  vec lvl_map[3], own_map[3];
+  vec lfm, lf_raw;
+};
+
+static int vec_reserve(vec *v, size_t bytes) {
+  if (bytes <= v->cap) return 0;
+  size_t ncap = v->cap ? v->cap : 4096;
+  while (ncap < bytes) ncap *= 2;
+  void *np = realloc(v->p, ncap);
+  if (!np) return -1;
+  v->p = np;
+  v->cap = ncap;
+  return 0;
+}
+
+int vp9hip_packer_create(vp9hip_packer **out) {
+  if (!out) return VP9HIP_EINVAL;
+  *out = (vp9hip_packer *)calloc(1, sizeof(vp9hip_packer));
+  return *out ? VP9HIP_OK : VP9HIP_ENOMEM;
+}
+
+void vp9hip_packer_destroy(vp9hip_packer *pk) {
+  if (!pk) return;
+  vec *all[] = { &pk->inter,    &pk->inter_sorted, &pk->txb,       &pk->txb_sorted, &pk->intra,    &pk->intra_isl,
+                 &pk->intra_big, &pk->islands,     &pk->wave_off,  &pk->big_wave_start, &pk->level, &pk->parent,
+                 &pk->comp_id,  &pk->comp_size,    &pk->order_a,   &pk->order_b,    &pk->count,    &pk->lvl_map[0],
+                 &pk->lvl_map[1], &pk->lvl_map[2], &pk->own_map[0], &pk->own_map[1], &pk->own_map[2], &pk->lfm,
+                 &pk->lf_raw };
+  for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) free(all[i]->p);
+  free(pk);
+}
+
+const char *vp9hip_packer_error(const vp9hip_packer *pk) { return pk ? pk->err : "null packer"; }
+
+#define PK_FAIL(pk, code, ...)                         \
+  do {                                                 \
+    snprintf((pk)->err, sizeof((pk)->err), __VA_ARGS__); \
+    return (code);                                     \
+  } while (0)
+
+/* ---- small libvpx helpers ---------------------------------------------------------------- */
+
+/* uv_txsize_lookup[bsize][tx][ss_x][ss_y] for ss = (1,1) and (0,0) (vp9_common_data.c): the
+ * largest transform that fits the chroma block, capped by the luma transform size. */
+static int uv_tx_size(int sb_type, int tx_size, int ss) {
+  if (sb_type < 3) return 0;
+  if (!ss) return tx_size;
+  int w4 = kW4[sb_type] >> 1, h4 = kH4[sb_type] >> 1;
+  int m = w4 < h4 ? w4 : h4, lg = 0;
+  if (m < 1) m = 1;
+  while ((2 << lg) <= m) ++lg;
+  return tx_size < lg ? tx_size : lg;
+}
+
+/* get_tile_offset / vp9_tile_set_col (vp9/common/vp9_tile_common.c:17-32): first mi column of the
+ * tile that contains mi_col. */
+static int tile_col_start(int mi_col, int mi_cols, int log2_tile_cols) {
+  const int sb_cols = (mi_cols + 7) >> 3;
+  const int n = 1 << log2_tile_cols;
+  int start = 0;
+  for (int t = 1; t < n; ++t) {
+    int off = ((t * sb_cols) >> log2_tile_cols) << 3;
+    if (off > mi_cols) off = mi_cols;
+    if (off <= mi_col) start = off;
+  }
+  return start;
+}
+
+/* round_mv_comp_q4 / round_mv_comp_q2 (vp9_reconinter.c:57-63, 73-79) */
+static int round_q4(int v) { return (v < 0 ? v - 2 : v + 2) / 4; }
+
+typedef struct {
+  int scaled;
+  int x_scale_fp, y_scale_fp; /* REF_SCALE_SHIFT = 14 (vp9_scale.h:21) */
+  int x_step_q4, y_step_q4;
+} scale_factors;
+
+static int scaled_x(int val, const scale_factors *sf) { return (int)((int64_t)val * sf->x_scale_fp >> 14); }
+static int scaled_y(int val, const scale_factors *sf) { return (int)((int64_t)val * sf->y_scale_fp >> 14); }
+
+/* vp9_setup_scale_factors_for_frame (vp9/common/vp9_scale.c:46-77); valid_ref_frame_size (:20 of
+ * vp9_scale.h: 2*this >= other, this <= 16*other) */
+static int setup_scale(scale_factors *sf, int other_w, int other_h, int this_w, int this_h) {
+  if (!(2 * this_w >= other_w && 2 * this_h >= other_h && this_w <= 16 * other_w && this_h <= 16 * other_h)) return -1;
+  sf->x_scale_fp = (other_w << 14) / this_w;
+  sf->y_scale_fp = (other_h << 14) / this_h;
+  sf->x_step_q4 = scaled_x(16, sf);
+  sf->y_step_q4 = scaled_y(16, sf);
+  sf->scaled = other_w != this_w || other_h != this_h; /* vp9_is_scaled: scale_fp != 1<<14 */
+  if (!sf->scaled) sf->x_scale_fp = sf->y_scale_fp = 1 << 14;
+  return 0;
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+/* ---- loop-filter masks -------------------------------------------------------------------- */
+
+typedef struct {
+  uint64_t left_y[4], above_y[4], int_4x4_y;
+  uint16_t left_uv[4], above_uv[4], int_4x4_uv;
+  uint8_t lfl_y[64];
+} lfm_raw;
+
+/* vp9_build_mask (vp9/common/vp9_loopfilter.c:1528-1608); the prediction/size masks are the
+ * rectangles its tables spell out (:80-195). */
+static void lf_build_mask(lfm_raw *lfm, const vp9hip_block *b) {
+  const int level = b->filter_level;
+  if (!level) return;
+  const int w8 = kW4[b->sb_type] > 1 ? kW4[b->sb_type] >> 1 : 1;
+  const int h8 = kH4[b->sb_type] > 1 ? kH4[b->sb_type] >> 1 : 1;
+  const int r0 = b->mi_row & 7, c0 = b->mi_col & 7;
+  const int shift_y = c0 + (r0 << 3), shift_uv = (c0 >> 1) + ((r0 >> 1) << 2);
+  const int build_uv = !(r0 & 1) && !(c0 & 1); /* first_block_in_16x16 */
+  const int txy = b->tx_size, txuv = uv_tx_size(b->sb_type, b->tx_size, 1);
+  const int wuv = w8 > 1 ? w8 >> 1 : 1, huv = h8 > 1 ? h8 >> 1 : 1;
+  uint64_t size_mask = 0, left_pred = 0;
+  uint32_t size_mask_uv = 0, left_pred_uv = 0;
+  for (int r = 0; r < h8; ++r) {
+    memset(&lfm->lfl_y[shift_y + 8 * r], level, (size_t)w8);
+    size_mask |= ((1ull << w8) - 1) << (8 * r);
+    left_pred |= 1ull << (8 * r);
+  }
+  for (int r = 0; r < huv; ++r) {
+    size_mask_uv |= ((1u << wuv) - 1) << (4 * r);
+    left_pred_uv |= 1u << (4 * r);
+  }
+  const uint64_t above_pred = (1ull << w8) - 1;
+  const uint32_t above_pred_uv = (1u << wuv) - 1;
+  lfm->above_y[txy] |= above_pred << shift_y;
+  lfm->left_y[txy] |= left_pred << shift_y;
+  if (build_uv) {
+    lfm->above_uv[txuv] |= (uint16_t)(above_pred_uv << shift_uv);
+    lfm->left_uv[txuv] |= (uint16_t)(left_pred_uv << shift_uv);
+  }
+  if (b->skip && b->ref_frame[0] > 0) return;
+  {
+    /* above_64x64_txform_mask / left_64x64_txform_mask (:39-78): rows / columns at multiples of the
+     * transform size */
+    const int t8 = (4 << txy) >> 3 ? (4 << txy) >> 3 : 1;
+    uint64_t rows_on = 0, cols_on = 0;
+    for (int r = 0; r < 8; r += t8) rows_on |= 0xffull << (8 * r);
+    for (int c = 0; c < 8; c += t8) cols_on |= 0x0101010101010101ull << c;
+    lfm->above_y[txy] |= (size_mask & rows_on) << shift_y;
+    lfm->left_y[txy] |= (size_mask & cols_on) << shift_y;
+  }
+  if (build_uv) {
+    const int tu = (4 << txuv) >> 3 ? (4 << txuv) >> 3 : 1;
+    uint32_t rows_uv = 0, cols_uv = 0;
+    for (int r = 0; r < 4; r += tu) rows_uv |= 0xfu << (4 * r);
+    for (int c = 0; c < 4; c += tu) cols_uv |= 0x1111u << c;
+    lfm->above_uv[txuv] |= (uint16_t)((size_mask_uv & rows_uv) << shift_uv);
+    lfm->left_uv[txuv] |= (uint16_t)((size_mask_uv & cols_uv) << shift_uv);
+  }
+  if (txy == 0) lfm->int_4x4_y |= size_mask << shift_y;
+  if (build_uv && txuv == 0) lfm->int_4x4_uv |= (uint16_t)((size_mask_uv & 0xffff) << shift_uv);
+}
+
+/* vp9_adjust_mask (vp9/common/vp9_loopfilter.c:766-880) */
+static void lf_adjust_mask(const lfm_raw *in, vp9hip_lfm *out, int mi_row, int mi_col, int mi_rows, int mi_cols) {
+  uint64_t ly[4], ay[4], iy = in->int_4x4_y;
+  uint16_t luv[4], auv[4], iuv = in->int_4x4_uv;
+  memcpy(ly, in->left_y, sizeof(ly));
+  memcpy(ay, in->above_y, sizeof(ay));
+  memcpy(luv, in->left_uv, sizeof(luv));
+  memcpy(auv, in->above_uv, sizeof(auv));
+  const uint64_t LB = 0x1111111111111111ull, AB = 0x000000ff000000ffull;
+  ly[2] |= ly[3];
+  ay[2] |= ay[3];
+  luv[2] |= luv[3];
+  auv[2] |= auv[3];
+  ly[1] |= ly[0] & LB;
+  ly[0] &= ~LB;
+  ay[1] |= ay[0] & AB;
+  ay[0] &= ~AB;
+  luv[1] |= luv[0] & 0x1111;
+  luv[0] &= (uint16_t)~0x1111;
+  auv[1] |= auv[0] & 0x000f;
+  auv[0] &= (uint16_t)~0x000f;
+  const int rows = mi_rows - mi_row, cols = mi_cols - mi_col;
+  if (rows < 8) {
+    const uint64_t my = (1ull << (rows << 3)) - 1;
+    const uint16_t muv = (uint16_t)((1u << (((rows + 1) >> 1) << 2)) - 1);
+    for (int k = 0; k < 3; ++k) {
+      ly[k] &= my;
+      ay[k] &= my;
+      luv[k] &= muv;
+      auv[k] &= muv;
+    }
+    iy &= my;
+    iuv &= muv;
+    if (rows == 1) {
+      auv[1] |= auv[2];
+      auv[2] = 0;
+    }
+    if (rows == 5) {
+      auv[1] |= auv[2] & 0xff00;
+      auv[2] &= (uint16_t)~(auv[2] & 0xff00);
+    }
+  }
+  if (cols < 8) {
+    const uint64_t my = ((1ull << cols) - 1) * 0x0101010101010101ull;
+    const uint16_t muv = (uint16_t)(((1u << ((cols + 1) >> 1)) - 1) * 0x1111);
+    const uint16_t muv_int = (uint16_t)(((1u << (cols >> 1)) - 1) * 0x1111);
+    for (int k = 0; k < 3; ++k) {
+      ly[k] &= my;
+      ay[k] &= my;
+      luv[k] &= muv;
+      auv[k] &= muv;
+    }
+    iy &= my;
+    iuv &= muv_int;
+    if (cols == 1) {
+      luv[1] |= luv[2];
+      luv[2] = 0;
+    }
+    if (cols == 5) {
+      luv[1] |= luv[2] & 0xcccc;
+      luv[2] &= (uint16_t)~(luv[2] & 0xcccc);
+    }
+  }
+  if (mi_col == 0) {
+    for (int k = 0; k < 3; ++k) {
+      ly[k] &= 0xfefefefefefefefeull;
+      luv[k] &= 0xeeee;
+    }
+  }
+  memset(out, 0, sizeof(*out));
+  for (int k = 0; k < 3; ++k) {
+    out->left_y[k] = ly[k];
+    out->above_y[k] = ay[k];
+    out->left_uv[k] = luv[k];
+    out->above_uv[k] = auv[k];
+  }
+  out->int_4x4_y = iy;
+  out->int_4x4_uv = iuv;
+  memcpy(out->lfl_y, in->lfl_y, 64);
+}
+
+void vp9hip_lf_frame_init(int default_lvl, int sharpness, const int32_t seg_enabled[8], const int32_t seg_data[8],
+                          int abs_delta, int mode_ref_delta_enabled, const int8_t ref_deltas[4],
+                          const int8_t mode_deltas[2], uint8_t out_lvl[8][4][2], vp9hip_lf_thresh *out_thresh) {
+  /* update_sharpness + vp9_loop_filter_init (vp9_loopfilter.c:212-250) */
+  if (out_thresh) {
+    for (int lvl = 0; lvl < 64; ++lvl) {
+      int lim = lvl >> ((sharpness > 0) + (sharpness > 4));
+      if (sharpness > 0 && lim > 9 - sharpness) lim = 9 - sharpness;
+      if (lim < 1) lim = 1;
+      out_thresh->lim[lvl] = (uint8_t)lim;
+      out_thresh->mblim[lvl] = (uint8_t)(2 * (lvl + 2) + lim);
+      out_thresh->hev_thr[lvl] = (uint8_t)(lvl >> 4);
+    }
+  }
+  if (!out_lvl) return;
+  /* vp9_loop_filter_frame_init (:252-295) */
+  const int scale = 1 << (default_lvl >> 5);
+  for (int s = 0; s < 8; ++s) {
+    int lvl_seg = default_lvl;
+    if (seg_enabled && seg_enabled[s]) lvl_seg = clampi(abs_delta ? seg_data[s] : default_lvl + seg_data[s], 0, 63);
+    if (!mode_ref_delta_enabled) {
+      memset(out_lvl[s], lvl_seg, 8);
+    } else {
+      out_lvl[s][0][0] = (uint8_t)clampi(lvl_seg + ref_deltas[0] * scale, 0, 63);
+      out_lvl[s][0][1] = 0; /* never read for intra (mode_lf_lut is 0 for intra modes); libvpx leaves it */
+      for (int ref = 1; ref < 4; ++ref)
+        for (int m = 0; m < 2; ++m)
+          out_lvl[s][ref][m] = (uint8_t)clampi(lvl_seg + ref_deltas[ref] * scale + mode_deltas[m] * scale, 0, 63);
+    }
+  }
+}
+
+/* ---- stable counting sort of fixed-size records by a small key ----------------------------- */
+static void counting_sort(const void *src, void *dst, size_t rec, const int32_t *key, int n, int n_keys,
+                          int32_t *count /* n_keys + 1 */) {
+  memset(count, 0, sizeof(int32_t) * (size_t)(n_keys + 1));
+  for (int i = 0; i < n; ++i) ++count[key[i] + 1];
+  for (int k = 0; k < n_keys; ++k) count[k + 1] += count[k];
+  for (int i = 0; i < n; ++i)
+    memcpy((char *)dst + (size_t)count[key[i]]++ * rec, (const char *)src + (size_t)i * rec, rec);
+}
+
+static int uf_find(int32_t *parent, int a) {
+  while (parent[a] != a) {
+    parent[a] = parent[parent[a]];
+    a = parent[a];
+  }
+  return a;
+}
+
+/* ---- the frame packer ---------------------------------------------------------------------- */
+
+int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9hip_block *blocks, int n_blocks,
+                      const vp9hip_coeff_layout *coeffs, vp9hip_packed *out) {
+  if (!pk) return VP9HIP_EINVAL;
+  if (!P || !out || n_blocks < 0 || (n_blocks && !blocks)) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: null argument");
+  if (P->width <= 0 || P->height <= 0 || P->width > 16384 || P->height > 16384)
+    PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: bad frame size %dx%d", P->width, P->height);
+  if (P->ss_x != P->ss_y || (P->ss_x != 0 && P->ss_x != 1))
+    PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: only 4:2:0 and 4:4:4 are supported (ss %d,%d)", P->ss_x, P->ss_y);
+  const int ss = P->ss_x;
+  const int aw = (P->width + 7) & ~7, ah = (P->height + 7) & ~7;
+  const int mi_cols = aw >> 3, mi_rows = ah >> 3;
+  const int sb_cols = (mi_cols + 7) >> 3, sb_rows = (mi_rows + 7) >> 3;
+  const int paw[3] = { aw, aw >> ss, aw >> ss }, pah[3] = { ah, ah >> ss, ah >> ss };
+  memset(out, 0, sizeof(*out));
+
+  scale_factors sf[3];
+  memset(sf, 0, sizeof(sf));
+  int sf_valid[3] = { 0, 0, 0 };
+  for (int r = 0; r < 3; ++r)
+    if (P->ref_width[r] > 0 && P->ref_height[r] > 0)
+      sf_valid[r] = setup_scale(&sf[r], P->ref_width[r], P->ref_height[r], P->width, P->height) == 0;
+
+  /* ---- pass 0: sizes ---------------------------------------------------------------------- */
+  size_t n_inter = 0, n_tx = 0;
+  int64_t coeff_count[3] = { 0, 0, 0 };
+  for (int i = 0; i < n_blocks; ++i) {
+    const vp9hip_block *b = &blocks[i];
+    if (b->sb_type > 12 || b->tx_size > 3 || b->mi_row < 0 || b->mi_col < 0 || b->mi_row >= mi_rows ||
+        b->mi_col >= mi_cols)
+      PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d out of range (sb_type %d tx %d at mi %d,%d)", i, b->sb_type,
+              b->tx_size, b->mi_row, b->mi_col);
+    const int bw8 = kW4[b->sb_type] > 1 ? kW4[b->sb_type] >> 1 : 1, bh8 = kH4[b->sb_type] > 1 ? kH4[b->sb_type] >> 1 : 1;
+    const int to_right = (mi_cols - bw8 - b->mi_col) * 64, to_bottom = (mi_rows - bh8 - b->mi_row) * 64;
+    const int inter = b->ref_frame[0] > 0;
+    if (inter) {
+      for (int r = 0; r < 1 + (b->ref_frame[1] > 0); ++r) {
+        const int k = b->ref_frame[r] - 1;
+        if (k < 0 || k > 2 || !sf_valid[k])
+          PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d uses reference %d which has no valid size", i, k + 1);
+      }
+      if (b->interp_filter > 3) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d bad interp_filter", i);
+      n_inter += b->sb_type < 3 ? (size_t)(4 + 2 * (ss ? 1 : 4)) : 3;
+    } else if (b->mode > 9 || b->uv_mode > 9) {
+      PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d bad intra mode", i);
+    }
+    for (int p = 0; p < 3; ++p) {
+      const int s = p ? ss : 0;
+      const int n4w = (bw8 * 2) >> s ? (bw8 * 2) >> s : 1, n4h = (bh8 * 2) >> s ? (bh8 * 2) >> s : 1;
+      const int tx = p ? uv_tx_size(b->sb_type, b->tx_size, ss) : b->tx_size;
+      const int mw = n4w + (to_right >= 0 ? 0 : to_right >> (5 + s)), mh = n4h + (to_bottom >= 0 ? 0 : to_bottom >> (5 + s));
+      const int step = 1 << tx;
+      const int cnt = ((mw + step - 1) / step) * ((mh + step - 1) / step);
+      if (mw <= 0 || mh <= 0) continue;
+      if (!inter || !b->skip) n_tx += (size_t)cnt;
+      if (!b->skip) coeff_count[p] += (int64_t)cnt * (16 << (2 * tx));
+    }
+  }
+  out->coeff_base[0] = 0;
+  out->coeff_base[1] = coeff_count[0];
+  out->coeff_base[2] = coeff_count[0] + coeff_count[1];
+  out->coeff_total = coeff_count[0] + coeff_count[1] + coeff_count[2];
+  memcpy(out->coeff_count, coeff_count, sizeof(coeff_count));
+  if (out->coeff_total > (int64_t)UINT32_MAX) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: too many coefficients");
+
+  if (vec_reserve(&pk->inter, (n_inter + 1) * sizeof(vp9hip_inter_task)) ||
+      vec_reserve(&pk->inter_sorted, (n_inter + 1) * sizeof(vp9hip_inter_task)) ||
+      vec_reserve(&pk->txb, (n_tx + 1) * sizeof(vp9hip_txb)) || vec_reserve(&pk->txb_sorted, (n_tx + 1) * sizeof(vp9hip_txb)) ||
+      vec_reserve(&pk->intra, (n_tx + 1) * sizeof(vp9hip_intra_task)) ||
+      vec_reserve(&pk->order_a, (n_tx + n_inter + 1) * sizeof(int32_t)))
+    PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+  vp9hip_inter_task *it = (vp9hip_inter_task *)pk->inter.p;
+  vp9hip_txb *tb = (vp9hip_txb *)pk->txb.p;
+  vp9hip_intra_task *ia = (vp9hip_intra_task *)pk->intra.p;
+  int32_t *key = (int32_t *)pk->order_a.p;
+  int ni = 0, nt = 0, na = 0;
+  int64_t run[3] = { 0, 0, 0 };
+  uint32_t refs_used = 0;
+
+  /* ---- pass 1: records in decode order ------------------------------------------------------ */
+  for (int i = 0; i < n_blocks; ++i) {
+    const vp9hip_block *b = &blocks[i];
+    const int bw8 = kW4[b->sb_type] > 1 ? kW4[b->sb_type] >> 1 : 1, bh8 = kH4[b->sb_type] > 1 ? kH4[b->sb_type] >> 1 : 1;
+    /* set_mi_row_col (vp9/common/vp9_onyxc_int.h): distances to the frame edges in 1/8 sample */
+    const int to_left = -(b->mi_col * 64), to_right = (mi_cols - bw8 - b->mi_col) * 64;
+    const int to_top = -(b->mi_row * 64), to_bottom = (mi_rows - bh8 - b->mi_row) * 64;
+    const int inter = b->ref_frame[0] > 0;
+    const int sub8 = b->sb_type < 3;
+    const int left_mi = b->mi_col > tile_col_start(b->mi_col, mi_cols, P->log2_tile_cols);
+
+    if (inter) {
+      const int compound = b->ref_frame[1] > 0;
+      for (int p = 0; p < 3; ++p) {
+        const int s = p ? ss : 0;
+        const int n4w = (bw8 * 2) >> s ? (bw8 * 2) >> s : 1, n4h = (bh8 * 2) >> s ? (bh8 * 2) >> s : 1;
+        const int bw = 4 * n4w, bh = 4 * n4h; /* plane block size as passed to dec_build_inter_predictors */
+        const int nby = sub8 ? n4h : 1, nbx = sub8 ? n4w : 1;
+        const int x_start = (b->mi_col * 8) >> s, y_start = (b->mi_row * 8) >> s;
+        for (int by = 0; by < nby; ++by)
+          for (int bx = 0; bx < nbx; ++bx) {
+            vp9hip_inter_task *t = &it[ni];
+            const int x = 4 * bx, y = 4 * by, blk = by * nbx + bx;
+            int any_scaled = 0;
+            memset(t, 0, sizeof(*t));
+            t->dst_x = (int16_t)(x_start + x);
+            t->dst_y = (int16_t)(y_start + y);
+            t->w = (uint8_t)(sub8 ? 4 : bw);
+            t->h = (uint8_t)(sub8 ? 4 : bh);
+            t->plane = (uint8_t)p;
+            t->flags = (uint8_t)(compound | (b->interp_filter << 1));
+            for (int r = 0; r < 1 + compound; ++r) {
+              const int k = b->ref_frame[r] - 1;
+              const scale_factors *f = &sf[k];
+              int mvr, mvc;
+              if (!sub8) {
+                mvr = b->mv[r][0];
+                mvc = b->mv[r][1];
+              } else if (!s) { /* average_split_mvs, ss_idx 0 */
+                mvr = b->sub_mv[blk][r][0];
+                mvc = b->sub_mv[blk][r][1];
+              } else { /* ss_idx 3: mi_mv_pred_q4 */
+                mvr = round_q4(b->sub_mv[0][r][0] + b->sub_mv[1][r][0] + b->sub_mv[2][r][0] + b->sub_mv[3][r][0]);
+                mvc = round_q4(b->sub_mv[0][r][1] + b->sub_mv[1][r][1] + b->sub_mv[2][r][1] + b->sub_mv[3][r][1]);
+              }
+              refs_used |= 1u << k;
+              t->ref[r] = (uint8_t)k;
+              if (!f->scaled) {
+                /* vp9_decodeframe.c:620-632: no clamp; q4 position = 16 * sample + mv in 1/16 */
+                t->pos_x[r] = ((x_start + x) << 4) + mvc * (1 << (1 - s));
+                t->pos_y[r] = ((y_start + y) << 4) + mvr * (1 << (1 - s));
+                t->step_x[r] = t->step_y[r] = 16;
+              } else {
+                /* vp9_decodeframe.c:566-619: clamp_mv_to_umv_border_sb, then scale */
+                const int spel_left = (4 + bw) << 4, spel_right = spel_left - 16;
+                const int spel_top = (4 + bh) << 4, spel_bottom = spel_top - 16;
+                int q4r = (int16_t)(mvr * (1 << (1 - s))), q4c = (int16_t)(mvc * (1 << (1 - s)));
+                q4c = clampi(q4c, to_left * (1 << (1 - s)) - spel_left, to_right * (1 << (1 - s)) + spel_right);
+                q4r = clampi(q4r, to_top * (1 << (1 - s)) - spel_top, to_bottom * (1 << (1 - s)) + spel_bottom);
+                /* vp9_scale_mv (vp9_scale.c:37-44) is given LUMA-grid block coordinates + the plane offset */
+                const int x_off_q4 = scaled_x((b->mi_col * 8 + x) << 4, f) & 15;
+                const int y_off_q4 = scaled_y((b->mi_row * 8 + y) << 4, f) & 15;
+                const int smv_c = scaled_x(q4c, f) + x_off_q4, smv_r = scaled_y(q4r, f) + y_off_q4;
+                t->pos_x[r] = (scaled_x(x_start + x, f) << 4) + smv_c;
+                t->pos_y[r] = (scaled_y(y_start + y, f) << 4) + smv_r;
+                t->step_x[r] = (uint8_t)f->x_step_q4;
+                t->step_y[r] = (uint8_t)f->y_step_q4;
+                any_scaled = 1;
+              }
+            }
+            if (!compound) {
+              t->step_x[1] = t->step_y[1] = 16;
+            }
+            {
+              int cls = 5;
+              if (!P->hbd && !any_scaled) cls = t->w == 4 ? 0 : t->w == 8 ? 1 : t->w == 16 ? 2 : t->w == 32 ? 3 : 4;
+              key[ni] = cls;
+            }
+            ++ni;
+          }
+      }
+    }
+
+    /* transform blocks: vp9_foreach_transformed_block_in_plane order, clipped to the frame */
+    for (int p = 0; p < 3; ++p) {
+      const int s = p ? ss : 0;
+      const int n4w = (bw8 * 2) >> s ? (bw8 * 2) >> s : 1, n4h = (bh8 * 2) >> s ? (bh8 * 2) >> s : 1;
+      const int tx = p ? uv_tx_size(b->sb_type, b->tx_size, ss) : b->tx_size;
+      const int mw = n4w + (to_right >= 0 ? 0 : to_right >> (5 + s)), mh = n4h + (to_bottom >= 0 ? 0 : to_bottom >> (5 + s));
+      const int step = 1 << tx, nn = 16 << (2 * tx);
+      const int x_start = (b->mi_col * 8) >> s, y_start = (b->mi_row * 8) >> s;
+      for (int row = 0; row < mh; row += step)
+        for (int col = 0; col < mw; col += step) {
+          const int x = x_start + 4 * col, y = y_start + 4 * row;
+          int eob = 0;
+          uint32_t off = 0;
+          if (!b->skip) {
+            off = (uint32_t)(out->coeff_base[p] + run[p]);
+            run[p] += nn;
+            if (coeffs && coeffs->eob[p]) eob = coeffs->eob[p][(size_t)y * coeffs->eob_stride[p] + x];
+            if (eob < 0 || eob > nn) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: bad eob %d (block %d plane %d)", eob, i, p);
+          }
+          if (inter) {
+            if (eob > 0) {
+              vp9hip_txb *r = &tb[nt++];
+              memset(r, 0, sizeof(*r));
+              r->coeff_off = off;
+              r->x = (uint16_t)x;
+              r->y = (uint16_t)y;
+              r->plane = (uint8_t)p;
+              r->tx_size = (uint8_t)tx;
+              r->tx_type = P->lossless ? 0x80 : 0;
+              r->eob = (uint16_t)eob;
+            }
+          } else {
+            vp9hip_intra_task *r = &ia[na++];
+            int mode = p ? b->uv_mode : b->mode;
+            if (sub8 && p == 0) mode = b->sub_mode[(row << 1) + col];
+            if (mode > 9) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d bad intra sub-mode", i);
+            memset(r, 0, sizeof(*r));
+            r->coeff_off = off;
+            r->x = (uint16_t)x;
+            r->y = (uint16_t)y;
+            r->plane = (uint8_t)p;
+            r->tx_size = (uint8_t)tx;
+            r->tx_type = P->lossless ? 0x80 : (uint8_t)((p || tx == 3) ? 0 : kModeToTxType[mode]);
+            r->mode = (uint8_t)mode;
+            r->eob = (uint16_t)eob;
+            /* vp9_predict_intra_block (vp9_reconintra.c:409-415) */
+            r->flags = (uint8_t)((row > 0 || b->mi_row > 0) | ((col > 0 || left_mi) << 1) | (((col + step) < n4w) << 2));
+          }
+        }
+    }
+  }
+  if (run[0] != coeff_count[0] || run[1] != coeff_count[1] || run[2] != coeff_count[2])
+    PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: internal coefficient count mismatch");
+
+  /* ---- inter tasks by class, residual records by size --------------------------------------- */
+  if (vec_reserve(&pk->count, sizeof(int32_t) * 16)) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+  int32_t *cnt = (int32_t *)pk->count.p;
+  counting_sort(it, pk->inter_sorted.p, sizeof(vp9hip_inter_task), key, ni, 6, cnt);
+  for (int k = 0; k < 6; ++k) out->inter_class_count[k] = 0;
+  for (int i = 0; i < ni; ++i) ++out->inter_class_count[key[i]];
+  out->inter = (const vp9hip_inter_task *)pk->inter_sorted.p;
+  out->n_inter = ni;
+  for (int i = 0; i < nt; ++i) key[i] = tb[i].tx_size;
+  counting_sort(tb, pk->txb_sorted.p, sizeof(vp9hip_txb), key, nt, 4, cnt);
+  for (int k = 0; k < 4; ++k) out->txb_size_count[k] = 0;
+  for (int i = 0; i < nt; ++i) ++out->txb_size_count[key[i]];
+  out->txb = (const vp9hip_txb *)pk->txb_sorted.p;
+  out->n_txb = nt;
+  out->refs_used = refs_used;
+
+  /* ---- intra: dependency levels + connected components --------------------------------------- */
+  out->intra_decode_order = ia;
+  out->n_intra = na;
+  if (vec_reserve(&pk->level, sizeof(int32_t) * (size_t)(na + 1)) || vec_reserve(&pk->parent, sizeof(int32_t) * (size_t)(na + 1)) ||
+      vec_reserve(&pk->comp_id, sizeof(int32_t) * (size_t)(na + 1)) || vec_reserve(&pk->comp_size, sizeof(int32_t) * (size_t)(na + 2)) ||
+      vec_reserve(&pk->order_b, sizeof(int32_t) * (size_t)(na + 1)) ||
+      vec_reserve(&pk->intra_isl, sizeof(vp9hip_intra_task) * (size_t)(na + 1)) ||
+      vec_reserve(&pk->intra_big, sizeof(vp9hip_intra_task) * (size_t)(na + 1)))
+    PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+  int32_t *lv = (int32_t *)pk->level.p, *parent = (int32_t *)pk->parent.p, *comp = (int32_t *)pk->comp_id.p;
+  int max_level = 0;
+  if (na) {
+    int32_t *lmap[3], *omap[3];
+    for (int p = 0; p < 3; ++p) {
+      const size_t cells = (size_t)(paw[p] >> 2) * (size_t)(pah[p] >> 2);
+      if (vec_reserve(&pk->lvl_map[p], cells * sizeof(int32_t)) || vec_reserve(&pk->own_map[p], cells * sizeof(int32_t)))
+        PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+      lmap[p] = (int32_t *)pk->lvl_map[p].p;
+      omap[p] = (int32_t *)pk->own_map[p].p;
+      memset(lmap[p], 0, cells * sizeof(int32_t));
+      memset(omap[p], 0xff, cells * sizeof(int32_t));
+    }
+    for (int i = 0; i < na; ++i) {
+      const vp9hip_intra_task *t = &ia[i];
+      const int p = t->plane, W = paw[p] >> 2, H = pah[p] >> 2;
+      const int cx = t->x >> 2, cy = t->y >> 2, n = 1 << t->tx_size;
+      int32_t *m = lmap[p], *o = omap[p];
+      int l = 0;
+      parent[i] = i;
+#define DEP(yy, xx)                                  \
+  do {                                               \
+    const size_t c_ = (size_t)(yy) * W + (xx);       \
+    if (m[c_] > l) l = m[c_];                        \
+    if (o[c_] >= 0) {                                \
+      const int ra_ = uf_find(parent, o[c_]), rb_ = uf_find(parent, i); \
+      if (ra_ != rb_) parent[rb_] = ra_;             \
+    }                                                \
+  } while (0)
+      if (t->flags & 2) /* left column */
+        for (int y = cy; y < cy + n && y < H; ++y) DEP(y, cx - 1);
+      if (t->flags & 1) { /* above row; 2*bs only for 4x4 with have_right (vp9_reconintra.c:349-393) */
+        const int ext = (n == 1 && (t->flags & 4)) ? 2 : n;
+        for (int x = cx; x < cx + ext && x < W; ++x) DEP(cy - 1, x);
+        if (t->flags & 2) DEP(cy - 1, cx - 1);
+      }
+#undef DEP
+      ++l;
+      lv[i] = l;
+      if (l > max_level) max_level = l;
+      for (int y = cy; y < cy + n && y < H; ++y)
+        for (int x = cx; x < cx + n && x < W; ++x) {
+          m[(size_t)y * W + x] = l;
+          o[(size_t)y * W + x] = i;
+        }
+    }
+  }
+  out->n_intra_waves = max_level;
+
+  /* dense component ids in order of first appearance, sizes */
+  int n_comp = 0;
+  int32_t *csize = (int32_t *)pk->comp_size.p;
+  {
+    int32_t *root_to_id = (int32_t *)pk->order_b.p;
+    for (int i = 0; i < na; ++i) root_to_id[i] = -1;
+    for (int i = 0; i < na; ++i) {
+      const int r = uf_find(parent, i);
+      if (root_to_id[r] < 0) {
+        root_to_id[r] = n_comp;
+        csize[n_comp++] = 0;
+      }
+      comp[i] = root_to_id[r];
+      ++csize[comp[i]];
+    }
+  }
+  /* split: islands (components that fit one workgroup's walk) / big components (global waves) */
+  {
+    vp9hip_intra_task *isl = (vp9hip_intra_task *)pk->intra_isl.p, *big = (vp9hip_intra_task *)pk->intra_big.p;
+    const size_t kmax = (size_t)(max_level > n_comp ? max_level : n_comp) + 2;
+    if (vec_reserve(&pk->count, sizeof(int32_t) * kmax) || vec_reserve(&pk->order_a, sizeof(int32_t) * (size_t)(2 * na + 2)) ||
+        vec_reserve(&pk->inter, sizeof(vp9hip_intra_task) * (size_t)(na + 1)))
+      PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+    cnt = (int32_t *)pk->count.p;
+    int32_t *k1 = (int32_t *)pk->order_a.p, *k2 = k1 + na + 1;
+    vp9hip_intra_task *tmp = (vp9hip_intra_task *)pk->inter.p; /* scratch: the unsorted inter list is dead */
+    int n_isl = 0, n_big = 0;
+    /* gather, keeping decode order */
+    for (int i = 0; i < na; ++i) {
+      if (csize[comp[i]] > MAX_ISLAND_TASKS) {
+        big[n_big] = ia[i];
+        k2[n_big++] = lv[i] - 1;
+      }
+    }
+    /* big: stable sort by level */
+    if (n_big) {
+      memcpy(tmp, big, sizeof(vp9hip_intra_task) * (size_t)n_big);
+      counting_sort(tmp, big, sizeof(vp9hip_intra_task), k2, n_big, max_level, cnt);
+    }
+    if (vec_reserve(&pk->big_wave_start, sizeof(int32_t) * (size_t)(max_level + 2)))
+      PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+    int32_t *bws = (int32_t *)pk->big_wave_start.p;
+    int n_big_waves = 0;
+    if (n_big) {
+      /* cnt[] after counting_sort holds the END offset of each key; rebuild starts */
+      memset(bws, 0, sizeof(int32_t) * (size_t)(max_level + 2));
+      for (int i = 0; i < n_big; ++i) ++bws[k2[i] + 1];
+      for (int k = 0; k < max_level; ++k) bws[k + 1] += bws[k];
+      n_big_waves = max_level;
+      while (n_big_waves > 0 && bws[n_big_waves] == bws[n_big_waves - 1]) --n_big_waves;
+    } else {
+      bws[0] = 0;
+    }
+    out->intra_big_tasks = big;
+    out->n_intra_big_tasks = n_big;
+    out->big_wave_start = bws;
+    out->n_big_waves = n_big_waves;
+
+    /* islands: sort by (component, level) = stable by level, then stable by component */
+    for (int i = 0; i < na; ++i) {
+      if (csize[comp[i]] <= MAX_ISLAND_TASKS) {
+        tmp[n_isl] = ia[i];
+        k1[n_isl] = lv[i] - 1;
+        k2[n_isl] = comp[i];
+        ++n_isl;
+      }
+    }
+    if (n_isl) {
+      /* sort (task, comp key) pairs by level: carry the comp key along by sorting an index */
+      if (vec_reserve(&pk->order_b, sizeof(int32_t) * (size_t)(3 * na + 3))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+      int32_t *idx = (int32_t *)pk->order_b.p, *idx2 = idx + na + 1, *kk = idx2 + na + 1;
+      for (int i = 0; i < n_isl; ++i) idx[i] = i;
+      counting_sort(idx, idx2, sizeof(int32_t), k1, n_isl, max_level, cnt);
+      for (int i = 0; i < n_isl; ++i) kk[i] = k2[idx2[i]];
+      counting_sort(idx2, idx, sizeof(int32_t), kk, n_isl, n_comp, cnt);
+      for (int i = 0; i < n_isl; ++i) isl[i] = tmp[idx[i]];
+      /* island records + wave offsets */
+      if (vec_reserve(&pk->islands, sizeof(vp9hip_intra_island) * (size_t)(n_comp + 1)) ||
+          vec_reserve(&pk->wave_off, sizeof(int32_t) * (size_t)(n_isl + n_comp + 2)))
+        PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+      vp9hip_intra_island *is = (vp9hip_intra_island *)pk->islands.p;
+      int32_t *wo = (int32_t *)pk->wave_off.p;
+      int n_is = 0, n_wo = 0, a = 0;
+      while (a < n_isl) {
+        const int c = k2[idx[a]];
+        int e = a;
+        vp9hip_intra_island *r = &is[n_is++];
+        r->task_start = (uint32_t)a;
+        r->wave_off_start = (uint32_t)n_wo;
+        r->n_waves = 0;
+        r->reserved = 0;
+        int prev = -1;
+        while (e < n_isl && k2[idx[e]] == c) {
+          const int l = k1[idx[e]];
+          if (l != prev) {
+            wo[n_wo++] = e - a;
+            ++r->n_waves;
+            prev = l;
+          }
+          ++e;
+        }
+        wo[n_wo++] = e - a;
+        a = e;
+      }
+      out->islands = is;
+      out->n_islands = n_is;
+      out->island_wave_off = wo;
+      out->n_island_wave_off = n_wo;
+    } else {
+      if (vec_reserve(&pk->wave_off, sizeof(int32_t) * 4)) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+      ((int32_t *)pk->wave_off.p)[0] = 0;
+      out->island_wave_off = (const int32_t *)pk->wave_off.p;
+      out->n_island_wave_off = 1;
+    }
+    out->intra_island_tasks = isl;
+    out->n_intra_island_tasks = n_isl;
+  }
+
+  /* ---- loop-filter masks ---------------------------------------------------------------------- */
+  out->sb_rows = sb_rows;
+  out->sb_cols = sb_cols;
+  if (P->build_lf_masks) {
+    const size_t n_sb = (size_t)sb_rows * sb_cols;
+    if (vec_reserve(&pk->lf_raw, n_sb * sizeof(lfm_raw)) || vec_reserve(&pk->lfm, n_sb * sizeof(vp9hip_lfm)))
+      PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+    lfm_raw *raw = (lfm_raw *)pk->lf_raw.p;
+    vp9hip_lfm *lfm = (vp9hip_lfm *)pk->lfm.p;
+    memset(raw, 0, n_sb * sizeof(lfm_raw));
+    for (int i = 0; i < n_blocks; ++i)
+      lf_build_mask(&raw[(size_t)(blocks[i].mi_row >> 3) * sb_cols + (blocks[i].mi_col >> 3)], &blocks[i]);
+    for (int r = 0; r < sb_rows; ++r)
+      for (int c = 0; c < sb_cols; ++c)
+        lf_adjust_mask(&raw[(size_t)r * sb_cols + c], &lfm[(size_t)r * sb_cols + c], r * 8, c * 8, mi_rows, mi_cols);
+    out->lfm = lfm;
+  }
+  return VP9HIP_OK;
+}

@@ -1,0 +1,145 @@
+/*
+ * vp9hip_pack.h — host-side packers of libvp9hip.so (plain C, no GPU calls): from the decoded
+ * mode information of one frame to the work lists of include/vp9hip.h.
+ *
+ * This is the reference's host logic on the reconstruction path,
+ * restated without libvpx types so that it sits behind a C-ABI:
+ *
+ *   inter tasks     dec_build_inter_predictors_sb / dec_build_inter_predictors
+ *                   (libvpx/vp9/decoder/vp9_decodeframe.c:556-800): one task per plane per
+ *                   prediction block, per 4x4 for sub-8x8 blocks with average_split_mvs
+ *                   (libvpx/vp9/common/vp9_reconinter.c:65-124); scaled references through
+ *                   clamp_mv_to_umv_border_sb + vp9_scale_mv (vp9_reconinter.c:90-110,
+ *                   vp9_scale.c:17-44); replaces createBuffers of the reference's GPU path
+ *                   (vpx-master/inter_cuda_kernel.cu:897-1028)
+ *   transform blocks   visit order and frame-edge clipping of detoken_block / inter_decode /
+ *                   intra_decode (vp9_decodeframe.c:919-1024, 1026-1071, 1150-1196 ==
+ *                   vp9_foreach_transformed_block_in_plane, vp9/common/vp9_blockd.c:37-75),
+ *                   uv transform size uv_txsize_lookup (vp9/common/vp9_common_data.c), tx_type
+ *                   intra_mode_to_tx_type_lookup (vp9/common/vp9_reconintra.c:24-35)
+ *   intra tasks     availability flags of vp9_predict_intra_block (vp9_reconintra.c:404-424)
+ *                   incl. the tile-column rule of set_mi_row_col (vp9_onyxc_int.h: left_mi is
+ *                   NULL at a tile's first column), dependency waves + islands; replaces
+ *                   createBuffersTr / globalCount / frameAnalyz / canDecodeHost
+ *                   (vpx-master/intra_cuda_kernel.cu:931-1304)
+ *   loop-filter masks   vp9_build_mask + vp9_adjust_mask (vp9/common/vp9_loopfilter.c:1528-1608,
+ *                   766-880), level tables vp9_loop_filter_frame_init (:252-295), thresholds
+ *                   update_sharpness / vp9_loop_filter_init (:212-250)
+ *
+ * The libvpx-side shim (shim/vp9hip_libvpx_shim.c) copies MODE_INFO fields into vp9hip_block
+ * records and calls these.  Only 4:2:0 and 4:4:4 with equal subsampling are accepted.
+ */
+#ifndef VP9HIP_PACK_H_
+#define VP9HIP_PACK_H_
+
+#include "vp9hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The subset of MODE_INFO (libvpx/vp9/common/vp9_blockd.h:74-97) the path reads, plus the
+ * block's position (ModeInfoBuf.mi_row / mi_col, vpx-master/buffers_struct.h:51-57).
+ * Records are in decode order. */
+typedef struct vp9hip_block {
+  int16_t mi_row, mi_col;  /* 8-pixel units */
+  uint8_t sb_type;         /* BLOCK_SIZE: 0 4X4, 1 4X8, 2 8X4, 3 8X8, 4 8X16, 5 16X8, 6 16X16,
+                              7 16X32, 8 32X16, 9 32X32, 10 32X64, 11 64X32, 12 64X64 */
+  uint8_t tx_size;         /* luma TX_SIZE 0..3 */
+  uint8_t skip;            /* mi->skip as parsed: no coefficients were read for the block */
+  uint8_t interp_filter;   /* 0 EIGHTTAP, 1 EIGHTTAP_SMOOTH, 2 EIGHTTAP_SHARP, 3 BILINEAR */
+  int8_t ref_frame[2];     /* [0]: 0 INTRA_FRAME, 1..3 LAST/GOLDEN/ALTREF; [1] <= 0: no second ref */
+  uint8_t mode;            /* intra y mode (blocks >= 8X8), PREDICTION_MODE 0..9 */
+  uint8_t uv_mode;
+  uint8_t sub_mode[4];     /* intra, sb_type < 8X8: bmi[i].as_mode */
+  uint8_t filter_level;    /* get_filter_level(): lvl[segment_id][ref_frame[0]][mode_lf_lut[mode]] */
+  uint8_t reserved[3];
+  int16_t mv[2][2];        /* [ref][0 row, 1 col], 1/8 luma sample (blocks >= 8X8) */
+  int16_t sub_mv[4][2][2]; /* sb_type < 8X8: bmi[i].as_mv[ref] */
+  uint8_t reserved2[4];
+} vp9hip_block; /* 64 bytes */
+
+typedef struct vp9hip_frame_params {
+  int32_t width, height;    /* luma crop size (cm->width / cm->height) */
+  int32_t ss_x, ss_y;       /* chroma subsampling: 1,1 or 0,0 */
+  int32_t bit_depth, hbd;   /* hbd: 16-bit sample storage (YV12_FLAG_HIGHBITDEPTH) */
+  int32_t lossless;         /* xd->lossless: WHT instead of DCT/ADST */
+  int32_t log2_tile_cols;   /* cm->log2_tile_cols (intra left availability stops at tile columns) */
+  /* reference i = LAST_FRAME + i: luma crop size of the reference frame (scaling when it differs
+   * from width/height; vp9_setup_scale_factors_for_frame, vp9_scale.c:46-77).  0 = unused. */
+  int32_t ref_width[3], ref_height[3];
+  int32_t build_lf_masks;   /* != 0: also build the loop-filter masks from the blocks */
+  int32_t reserved[3];
+} vp9hip_frame_params;
+
+/* Where the coefficients of the frame are, in the reference's layout
+ * (frameBuf, vpx-master/buffers_struct.h:9-15, filled by detoken_block):
+ *   - per plane one array of concatenated N*N blocks in decode order, one slot for EVERY visited
+ *     transform block of every non-skip block (also those with eob 0);
+ *   - eob[plane][y * eob_stride[plane] + x] at each transform block's top-left sample. */
+typedef struct vp9hip_coeff_layout {
+  const int32_t *eob[3];
+  int32_t eob_stride[3];
+} vp9hip_coeff_layout;
+
+typedef struct vp9hip_packed {
+  /* inter prediction, sorted into the six classes of vp9hip_inter_pred_batch */
+  const vp9hip_inter_task *inter;
+  int32_t n_inter, inter_class_count[6];
+  /* residual of inter blocks, sorted by transform size (vp9hip_idct_add_batch) */
+  const vp9hip_txb *txb;
+  int32_t n_txb, txb_size_count[4];
+  /* intra: islands (vp9hip_intra_pred_islands) + the remainder of very large components as
+   * global waves (vp9hip_intra_pred_waves); intra_decode_order is the same set in decode order */
+  const vp9hip_intra_task *intra_island_tasks;
+  int32_t n_intra_island_tasks;
+  const vp9hip_intra_island *islands;
+  int32_t n_islands;
+  const int32_t *island_wave_off;
+  int32_t n_island_wave_off;
+  const vp9hip_intra_task *intra_big_tasks;
+  int32_t n_intra_big_tasks;
+  const int32_t *big_wave_start; /* n_big_waves + 1 entries */
+  int32_t n_big_waves;
+  const vp9hip_intra_task *intra_decode_order;
+  int32_t n_intra;
+  int32_t n_intra_waves; /* depth of the whole dependency graph */
+  /* coefficient slots: plane p's array starts at coeff_base[p] (in coefficients) of one
+   * concatenated buffer of coeff_total entries; records' coeff_off already include it */
+  int64_t coeff_base[3], coeff_count[3], coeff_total;
+  /* loop filter (only when params.build_lf_masks) */
+  const vp9hip_lfm *lfm;
+  int32_t sb_rows, sb_cols;
+  /* which references (bit i = LAST_FRAME + i) inter tasks read */
+  uint32_t refs_used;
+} vp9hip_packed;
+
+typedef struct vp9hip_packer vp9hip_packer;
+
+/* A packer owns growable host arrays that are reused from frame to frame (the reference mallocs
+ * and frees its lists for every frame, vp9_decodeframe.c:2316-2330, 2625-2634). */
+int vp9hip_packer_create(vp9hip_packer **out);
+void vp9hip_packer_destroy(vp9hip_packer *pk);
+const char *vp9hip_packer_error(const vp9hip_packer *pk);
+
+/* Packs one frame.  `out` points into the packer's arrays and stays valid until the next call.
+ * coeffs may be NULL: then every non-skip transform block is emitted with eob 0 is NOT assumed —
+ * instead NO residual records are produced (prediction only; the residual-plane mode of the
+ * shim).  Returns VP9HIP_OK or VP9HIP_EINVAL / VP9HIP_ENOMEM. */
+int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *params, const vp9hip_block *blocks,
+                      int n_blocks, const vp9hip_coeff_layout *coeffs, vp9hip_packed *out);
+
+/* Loop-filter level table and thresholds of a frame (vp9_loop_filter_frame_init +
+ * update_sharpness, vp9_loopfilter.c:212-295).
+ *   seg_lvl[s]: INT32_MIN-free encoding: seg_enabled[s] != 0 -> seg_data[s] is the SEG_LVL_ALT_LF
+ *   value of segment s; abs_delta != 0 -> absolute, else added to default_lvl.
+ *   ref_deltas[4], mode_deltas[2] used when mode_ref_delta_enabled.
+ * out_lvl[8][4][2] as loop_filter_info_n.lvl. */
+void vp9hip_lf_frame_init(int default_lvl, int sharpness, const int32_t seg_enabled[8], const int32_t seg_data[8],
+                          int abs_delta, int mode_ref_delta_enabled, const int8_t ref_deltas[4],
+                          const int8_t mode_deltas[2], uint8_t out_lvl[8][4][2], vp9hip_lf_thresh *out_thresh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP9HIP_PACK_H_ */
