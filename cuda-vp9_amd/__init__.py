@@ -63,7 +63,8 @@ class FrameParams(ctypes.Structure):
                 ("ss_y", ctypes.c_int32), ("bit_depth", ctypes.c_int32), ("hbd", ctypes.c_int32),
                 ("lossless", ctypes.c_int32), ("log2_tile_cols", ctypes.c_int32),
                 ("ref_width", ctypes.c_int32 * 3), ("ref_height", ctypes.c_int32 * 3),
-                ("build_lf_masks", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+                ("build_lf_masks", ctypes.c_int32), ("assume_coded", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2)]
 
 
 class CoeffLayout(ctypes.Structure):

@@ -191,6 +191,9 @@ __device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t,
 #pragma unroll
       for (int k = 0; k < N; ++k) v[k] = e;
       v[0] = ip - e;
+    } else if (tk.tx_type & 0x40) {  // residual given directly (residual-plane mode), raster NxN
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = tile[k * TPITCH + t];
     } else {
       col_pass<N, HBD>(tile, t, tk.tx_type & 3, tk.tx_type & 0x80, v);
     }
@@ -221,6 +224,7 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
   const int bs = 4 << tk.tx_size;
   const int pl = tk.plane;
   const bool lossless = tk.tx_type & 0x80;
+  const bool identity = tk.tx_type & 0x40;  // the "coefficients" are already the residual
   // coded: residual present; eob<=1 blocks take the DC-only forms (vp9_idct.c:119-204)
   const bool coded = active && coeffs != nullptr && tk.eob > 0;
   int *E = edge[slot] + EOFF;
@@ -269,8 +273,10 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
     }
     if (coded) {
       const int32_t *src = coeffs + tk.coeff_off;
-      if (!lossless && ((tk.tx_type & 3) == 0 || bs == 32) && (bs == 4 ? tk.eob <= 1 : tk.eob == 1)) dc_kind = 1;
-      if (lossless && tk.eob <= 1) dc_kind = 2;
+      if (!identity) {
+        if (!lossless && ((tk.tx_type & 3) == 0 || bs == 32) && (bs == 4 ? tk.eob <= 1 : tk.eob == 1)) dc_kind = 1;
+        if (lossless && tk.eob <= 1) dc_kind = 2;
+      }
       if (dc_kind)
         dc_coeff = src[0];  // only the DC term is defined (and read) at eob <= 1
       else if (t < bs)
@@ -278,7 +284,7 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
     }
   }
   __syncthreads();
-  if (coded && !dc_kind && t < bs) {
+  if (coded && !dc_kind && !identity && t < bs) {
     const int tt = tk.tx_type & 3;
     switch (tk.tx_size) {
       case 0: row_pass<4, HBD>(tile, t, tt, lossless); break;

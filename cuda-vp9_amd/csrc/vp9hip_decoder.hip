@@ -1,0 +1,457 @@
+// vp9hip_decoder.hip — frame-level driver (see include/vp9hip_decoder.h): device frame pool,
+// work-list / coefficient transfers, phase sequencing.  C-style host code + two small kernels for
+// the residual-plane mode.  Reference citations are relative to /root/reference/.
+#include <stdlib.h>
+
+#include "../../include/vp9hip_decoder.h"
+#include "vp9hip_internal.h"
+
+namespace {
+
+struct DevVec {
+  void *p;
+  size_t cap;
+};
+
+struct Slot {
+  vp9hip_frame f;
+  size_t bytes[3];
+  int ss;
+  bool used;
+};
+
+}  // namespace
+
+struct vp9hip_decoder {
+  vp9hip_ctx *ctx;
+  vp9hip_packer *pk;
+  char err[512];
+  Slot slots[VP9HIP_POOL_SLOTS];
+  DevVec d_inter, d_txb, d_isl_tasks, d_islands, d_wave_off, d_big_tasks, d_lfm, d_coeffs, d_res[3];
+  int32_t res_stride[3];
+  bool have_res;
+  bool begun;
+  bool have_coeffs;
+  vp9hip_frame_params params;
+  vp9hip_packed packed;
+  int32_t *big_wave_start;  // host copy (the packer's array is reused by the next frame)
+  size_t big_wave_cap;
+  bool timed;
+};
+
+#define DEC_FAIL(dec, code, ...)                              \
+  do {                                                        \
+    snprintf((dec)->err, sizeof((dec)->err), __VA_ARGS__);    \
+    return (code);                                            \
+  } while (0)
+
+#define DEC_HIP(dec, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      DEC_FAIL(dec, VP9HIP_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// propagate an error of the batched layer
+#define DEC_CTX(dec, expr)                                                       \
+  do {                                                                           \
+    int rc_ = (expr);                                                            \
+    if (rc_ != VP9HIP_OK) DEC_FAIL(dec, rc_, "%s", vp9hip_last_error((dec)->ctx)); \
+  } while (0)
+
+static const int TIMER_RUN = VP9HIP_TIMER_SLOTS - 1;
+
+static int dv_reserve(vp9hip_decoder *dec, DevVec *v, size_t bytes) {
+  if (bytes <= v->cap) return VP9HIP_OK;
+  DEC_HIP(dec, hipStreamSynchronize(dec->ctx->stream));
+  if (v->p) (void)hipFree(v->p);
+  v->p = NULL;
+  v->cap = 0;
+  size_t want = bytes + (bytes >> 2) + 256;
+  DEC_HIP(dec, hipMalloc(&v->p, want));
+  v->cap = want;
+  return VP9HIP_OK;
+}
+
+static int dv_upload(vp9hip_decoder *dec, DevVec *v, const void *src, size_t bytes) {
+  int rc = dv_reserve(dec, v, bytes ? bytes : 16);
+  if (rc) return rc;
+  if (bytes) DEC_HIP(dec, hipMemcpyAsync(v->p, src, bytes, hipMemcpyHostToDevice, dec->ctx->stream));
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_decoder_create(int device, vp9hip_decoder **out) {
+  if (!out) return VP9HIP_EINVAL;
+  *out = NULL;
+  vp9hip_decoder *dec = (vp9hip_decoder *)calloc(1, sizeof(*dec));
+  if (!dec) return VP9HIP_ENOMEM;
+  int rc = vp9hip_create(device, &dec->ctx);
+  if (rc) {
+    free(dec);
+    return rc;  // text in vp9hip_last_error(NULL)
+  }
+  rc = vp9hip_packer_create(&dec->pk);
+  if (rc) {
+    vp9hip_destroy(dec->ctx);
+    free(dec);
+    return rc;
+  }
+  *out = dec;
+  return VP9HIP_OK;
+}
+
+extern "C" void vp9hip_decoder_destroy(vp9hip_decoder *dec) {
+  if (!dec) return;
+  (void)hipSetDevice(dec->ctx->device);
+  (void)hipStreamSynchronize(dec->ctx->stream);
+  for (int s = 0; s < VP9HIP_POOL_SLOTS; ++s)
+    for (int p = 0; p < 3; ++p)
+      if (dec->slots[s].f.plane[p]) (void)hipFree(dec->slots[s].f.plane[p]);
+  DevVec *all[] = { &dec->d_inter, &dec->d_txb, &dec->d_isl_tasks, &dec->d_islands, &dec->d_wave_off, &dec->d_big_tasks,
+                    &dec->d_lfm,   &dec->d_coeffs, &dec->d_res[0], &dec->d_res[1], &dec->d_res[2] };
+  for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i)
+    if (all[i]->p) (void)hipFree(all[i]->p);
+  free(dec->big_wave_start);
+  vp9hip_packer_destroy(dec->pk);
+  vp9hip_destroy(dec->ctx);
+  free(dec);
+}
+
+extern "C" const char *vp9hip_decoder_error(const vp9hip_decoder *dec) {
+  return dec ? dec->err : vp9hip_last_error(NULL);
+}
+
+extern "C" vp9hip_ctx *vp9hip_decoder_ctx(vp9hip_decoder *dec) { return dec ? dec->ctx : NULL; }
+
+extern "C" int vp9hip_decoder_alloc_slot(vp9hip_decoder *dec, int slot, int width, int height, int ss, int bit_depth,
+                                         int hbd, int clear) {
+  if (!dec) return VP9HIP_EINVAL;
+  if (slot < 0 || slot >= VP9HIP_POOL_SLOTS) DEC_FAIL(dec, VP9HIP_EINVAL, "pool slot %d out of range", slot);
+  if (width <= 0 || height <= 0 || width > 16384 || height > 16384 || (ss != 0 && ss != 1) ||
+      (bit_depth != 8 && bit_depth != 10 && bit_depth != 12) || (bit_depth > 8 && !hbd))
+    DEC_FAIL(dec, VP9HIP_EINVAL, "bad frame geometry %dx%d ss %d bd %d hbd %d", width, height, ss, bit_depth, hbd);
+  DEC_HIP(dec, hipSetDevice(dec->ctx->device));
+  Slot *s = &dec->slots[slot];
+  const int aw = (width + 7) & ~7, ah = (height + 7) & ~7;
+  const int bps = hbd ? 2 : 1;
+  vp9hip_frame f;
+  memset(&f, 0, sizeof(f));
+  f.bit_depth = bit_depth;
+  f.hbd = hbd ? 1 : 0;
+  for (int p = 0; p < 3; ++p) {
+    const int sh = p ? ss : 0;
+    f.width[p] = (width + sh) >> sh;
+    f.height[p] = (height + sh) >> sh;
+    f.awidth[p] = aw >> sh;
+    f.aheight[p] = ah >> sh;
+    f.stride[p] = (f.awidth[p] + 63) & ~63;
+  }
+  bool same = s->used && s->f.bit_depth == f.bit_depth && s->f.hbd == f.hbd && s->ss == ss;
+  for (int p = 0; p < 3 && same; ++p)
+    same = s->f.width[p] == f.width[p] && s->f.height[p] == f.height[p] && s->f.stride[p] == f.stride[p];
+  if (!same) {
+    DEC_HIP(dec, hipStreamSynchronize(dec->ctx->stream));
+    for (int p = 0; p < 3; ++p) {
+      const size_t need = (size_t)f.stride[p] * f.aheight[p] * bps;
+      if (need > s->bytes[p]) {
+        if (s->f.plane[p]) (void)hipFree(s->f.plane[p]);
+        s->f.plane[p] = NULL;
+        s->bytes[p] = 0;
+        DEC_HIP(dec, hipMalloc(&s->f.plane[p], need));
+        s->bytes[p] = need;
+      }
+      f.plane[p] = s->f.plane[p];
+    }
+    s->f = f;
+    s->ss = ss;
+    s->used = true;
+  }
+  if (clear)
+    for (int p = 0; p < 3; ++p)
+      DEC_HIP(dec, hipMemsetAsync(s->f.plane[p], 0, (size_t)s->f.stride[p] * s->f.aheight[p] * bps, dec->ctx->stream));
+  return VP9HIP_OK;
+}
+
+static int host_frame_ok(const vp9hip_host_frame *h) {
+  return h && h->plane[0] && h->plane[1] && h->plane[2] && h->ss_x == h->ss_y;
+}
+
+extern "C" int vp9hip_decoder_upload(vp9hip_decoder *dec, int slot, const vp9hip_host_frame *src) {
+  if (!dec) return VP9HIP_EINVAL;
+  if (!host_frame_ok(src)) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_upload: bad host frame");
+  int rc = vp9hip_decoder_alloc_slot(dec, slot, src->width, src->height, src->ss_x, src->bit_depth, src->hbd, 0);
+  if (rc) return rc;
+  const Slot *s = &dec->slots[slot];
+  const int bps = src->hbd ? 2 : 1;
+  for (int p = 0; p < 3; ++p) {
+    if (src->stride[p] < s->f.awidth[p]) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_upload: plane %d stride too small", p);
+    DEC_HIP(dec, hipMemcpy2DAsync(s->f.plane[p], (size_t)s->f.stride[p] * bps, src->plane[p], (size_t)src->stride[p] * bps,
+                                  (size_t)s->f.awidth[p] * bps, s->f.aheight[p], hipMemcpyHostToDevice, dec->ctx->stream));
+  }
+  DEC_HIP(dec, hipStreamSynchronize(dec->ctx->stream));
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_decoder_download(vp9hip_decoder *dec, int slot, const vp9hip_host_frame *dst) {
+  if (!dec) return VP9HIP_EINVAL;
+  if (slot < 0 || slot >= VP9HIP_POOL_SLOTS || !dec->slots[slot].used)
+    DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download: slot %d holds no frame", slot);
+  if (!host_frame_ok(dst)) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download: bad host frame");
+  const Slot *s = &dec->slots[slot];
+  if (dst->width != s->f.width[0] || dst->height != s->f.height[0] || (dst->hbd != 0) != (s->f.hbd != 0) ||
+      dst->ss_x != s->ss)
+    DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download: host frame geometry differs from slot %d", slot);
+  const int bps = s->f.hbd ? 2 : 1;
+  DEC_HIP(dec, hipSetDevice(dec->ctx->device));
+  for (int p = 0; p < 3; ++p) {
+    if (dst->stride[p] < s->f.awidth[p]) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download: plane %d stride too small", p);
+    DEC_HIP(dec, hipMemcpy2DAsync(dst->plane[p], (size_t)dst->stride[p] * bps, s->f.plane[p], (size_t)s->f.stride[p] * bps,
+                                  (size_t)s->f.awidth[p] * bps, s->f.aheight[p], hipMemcpyDeviceToHost, dec->ctx->stream));
+  }
+  int rc = vp9hip_sync(dec->ctx);
+  if (rc) DEC_FAIL(dec, rc, "%s", vp9hip_last_error(dec->ctx));
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_decoder_slot_frame(vp9hip_decoder *dec, int slot, vp9hip_frame *out) {
+  if (!dec || !out) return VP9HIP_EINVAL;
+  if (slot < 0 || slot >= VP9HIP_POOL_SLOTS || !dec->slots[slot].used)
+    DEC_FAIL(dec, VP9HIP_EINVAL, "slot %d holds no frame", slot);
+  *out = dec->slots[slot].f;
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_decoder_begin_frame(vp9hip_decoder *dec, const vp9hip_frame_params *params,
+                                          const vp9hip_block *blocks, int n_blocks, const vp9hip_coeff_layout *layout,
+                                          const int32_t *const dqcoeff[3]) {
+  if (!dec) return VP9HIP_EINVAL;
+  if (!params) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: null params");
+  if (dqcoeff && !layout) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: dqcoeff without the eob layout");
+  dec->begun = false;
+  dec->have_res = false;
+  DEC_HIP(dec, hipSetDevice(dec->ctx->device));
+  // the packer's arrays may still be the source of an in-flight copy of the previous frame
+  DEC_HIP(dec, hipStreamSynchronize(dec->ctx->stream));
+  int rc = vp9hip_pack_frame(dec->pk, params, blocks, n_blocks, layout, &dec->packed);
+  if (rc) DEC_FAIL(dec, rc, "%s", vp9hip_packer_error(dec->pk));
+  const vp9hip_packed *P = &dec->packed;
+  dec->params = *params;
+  if ((rc = dv_upload(dec, &dec->d_inter, P->inter, sizeof(vp9hip_inter_task) * (size_t)P->n_inter))) return rc;
+  if ((rc = dv_upload(dec, &dec->d_txb, P->txb, sizeof(vp9hip_txb) * (size_t)P->n_txb))) return rc;
+  if ((rc = dv_upload(dec, &dec->d_isl_tasks, P->intra_island_tasks, sizeof(vp9hip_intra_task) * (size_t)P->n_intra_island_tasks)))
+    return rc;
+  if ((rc = dv_upload(dec, &dec->d_islands, P->islands, sizeof(vp9hip_intra_island) * (size_t)P->n_islands))) return rc;
+  if ((rc = dv_upload(dec, &dec->d_wave_off, P->island_wave_off, sizeof(int32_t) * (size_t)P->n_island_wave_off))) return rc;
+  if ((rc = dv_upload(dec, &dec->d_big_tasks, P->intra_big_tasks, sizeof(vp9hip_intra_task) * (size_t)P->n_intra_big_tasks)))
+    return rc;
+  if (P->lfm && (rc = dv_upload(dec, &dec->d_lfm, P->lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols))) return rc;
+  if ((size_t)(P->n_big_waves + 1) > dec->big_wave_cap) {
+    free(dec->big_wave_start);
+    dec->big_wave_cap = (size_t)P->n_big_waves + 64;
+    dec->big_wave_start = (int32_t *)malloc(sizeof(int32_t) * dec->big_wave_cap);
+    if (!dec->big_wave_start) {
+      dec->big_wave_cap = 0;
+      DEC_FAIL(dec, VP9HIP_ENOMEM, "out of host memory");
+    }
+  }
+  memcpy(dec->big_wave_start, P->big_wave_start, sizeof(int32_t) * (size_t)(P->n_big_waves + 1));
+  if ((rc = dv_reserve(dec, &dec->d_coeffs, sizeof(int32_t) * (size_t)(P->coeff_total + 16)))) return rc;
+  dec->have_coeffs = dqcoeff != NULL;
+  if (dqcoeff)
+    for (int p = 0; p < 3; ++p)
+      if (P->coeff_count[p]) {
+        if (!dqcoeff[p]) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: dqcoeff[%d] is null", p);
+        DEC_HIP(dec, hipMemcpyAsync((int32_t *)dec->d_coeffs.p + P->coeff_base[p], dqcoeff[p],
+                                    sizeof(int32_t) * (size_t)P->coeff_count[p], hipMemcpyHostToDevice, dec->ctx->stream));
+      }
+  // the host arrays (packer's, caller's) may be reused as soon as this returns
+  DEC_HIP(dec, hipStreamSynchronize(dec->ctx->stream));
+  dec->begun = true;
+  return VP9HIP_OK;
+}
+
+// ---- residual-plane mode ----------------------------------------------------------------------
+namespace {
+
+// dst = clip(dst + residual) over a whole plane: the reference's block_sum / inter_residual_sum
+// (libvpx/vp9/decoder/vp9_decodeframe.c:290-341, 1117-1148; vpx-master/inter_cuda_kernel.cu:821-829)
+// for every sample at once — the residual plane is zero where nothing was coded.
+__global__ __launch_bounds__(256) void residual_add_plane_kernel(uint16_t *__restrict__ dst, int dstride,
+                                                                 const int64_t *__restrict__ res, int rstride, int w, int h,
+                                                                 int maxv) {
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  // two samples per lane: one 32-bit pixel access, one 16-byte residual access (w is a multiple of 4)
+  const longlong2 r = *(const longlong2 *)(res + (size_t)y * rstride + x);
+  uint32_t *dp = (uint32_t *)(dst + (size_t)y * dstride + x);
+  const uint32_t px = *dp;
+  int a = (int)(px & 0xffff) + (int)r.x, b = (int)(px >> 16) + (int)r.y;
+  a = a < 0 ? 0 : a > maxv ? maxv : a;
+  b = b < 0 ? 0 : b > maxv ? maxv : b;
+  *dp = (uint32_t)a | ((uint32_t)b << 16);
+}
+
+// Gather the residual of every coded intra transform block into its coefficient slot (int32,
+// raster N x N) so that the intra kernel can add it right after predicting the block
+// (tx_type bit 6).  One workgroup per task.
+__global__ __launch_bounds__(256) void residual_gather_kernel(const vp9hip_intra_task *__restrict__ tasks, int n,
+                                                              const int64_t *r0, const int64_t *r1, const int64_t *r2,
+                                                              int s0, int s1, int s2, int h0, int h12,
+                                                              int32_t *__restrict__ coeffs) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const vp9hip_intra_task tk = tasks[i];
+  if (tk.eob == 0) return;
+  const int bs = 4 << tk.tx_size;
+  const int64_t *res = tk.plane == 0 ? r0 : tk.plane == 1 ? r1 : r2;
+  const int rs = tk.plane == 0 ? s0 : tk.plane == 1 ? s1 : s2;  // = plane width on the device
+  const int ph = tk.plane == 0 ? h0 : h12;
+  for (int k = threadIdx.x; k < bs * bs; k += 256) {
+    const int r = k / bs, c = k % bs;
+    // a block may overhang the aligned plane; only its visible part is stored (and later written)
+    const bool in = tk.y + r < ph && tk.x + c < rs;
+    coeffs[tk.coeff_off + k] = in ? (int32_t)res[(size_t)(tk.y + r) * rs + tk.x + c] : 0;
+  }
+}
+
+__global__ void mark_identity_kernel(vp9hip_intra_task *tasks, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) tasks[i].tx_type |= 0x40;
+}
+
+}  // namespace
+
+extern "C" int vp9hip_decoder_set_residual_planes(vp9hip_decoder *dec, const int64_t *const res[3],
+                                                  const int32_t stride[3]) {
+  if (!dec) return VP9HIP_EINVAL;
+  if (!dec->begun) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_set_residual_planes: no frame begun");
+  if (!res || !stride || !res[0] || !res[1] || !res[2]) DEC_FAIL(dec, VP9HIP_EINVAL, "null residual plane");
+  if (!dec->params.hbd)
+    DEC_FAIL(dec, VP9HIP_EINVAL,
+             "residual-plane mode needs a high-bitdepth frame (the reference's CPU transforms only produce int64 "
+             "residuals on their highbd path); pass the coefficient buffers to vp9hip_decoder_begin_frame instead");
+  if (dec->have_coeffs) DEC_FAIL(dec, VP9HIP_EINVAL, "coefficients were already given for this frame");
+  const int aw = (dec->params.width + 7) & ~7, ah = (dec->params.height + 7) & ~7, ss = dec->params.ss_x;
+  DEC_HIP(dec, hipSetDevice(dec->ctx->device));
+  for (int p = 0; p < 3; ++p) {
+    const int w = p ? aw >> ss : aw, h = p ? ah >> ss : ah;
+    if (stride[p] < w) DEC_FAIL(dec, VP9HIP_EINVAL, "residual plane %d stride too small", p);
+    int rc = dv_reserve(dec, &dec->d_res[p], sizeof(int64_t) * (size_t)w * h);
+    if (rc) return rc;
+    dec->res_stride[p] = w;
+    DEC_HIP(dec, hipMemcpy2DAsync(dec->d_res[p].p, sizeof(int64_t) * (size_t)w, res[p], sizeof(int64_t) * (size_t)stride[p],
+                                  sizeof(int64_t) * (size_t)w, h, hipMemcpyHostToDevice, dec->ctx->stream));
+  }
+  DEC_HIP(dec, hipStreamSynchronize(dec->ctx->stream));
+  dec->have_res = true;
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref_slot[3], int dst_slot,
+                                  const vp9hip_lfm *h_lfm, const vp9hip_lf_thresh *thresh) {
+  if (!dec) return VP9HIP_EINVAL;
+  if (!dec->begun) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: no frame begun");
+  if (dst_slot < 0 || dst_slot >= VP9HIP_POOL_SLOTS || !dec->slots[dst_slot].used)
+    DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: destination slot %d holds no frame", dst_slot);
+  const vp9hip_packed *P = &dec->packed;
+  const vp9hip_frame *dst = &dec->slots[dst_slot].f;
+  if (dst->width[0] != dec->params.width || dst->height[0] != dec->params.height || dst->hbd != (dec->params.hbd ? 1 : 0) ||
+      dst->bit_depth != dec->params.bit_depth)
+    DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: destination slot geometry differs from the frame parameters");
+  DEC_HIP(dec, hipSetDevice(dec->ctx->device));
+  hipStream_t st = dec->ctx->stream;
+  DEC_CTX(dec, vp9hip_timer_begin(dec->ctx, TIMER_RUN));
+
+  if ((phases & VP9HIP_PHASE_INTER)) {
+    if (P->n_inter) {
+      vp9hip_frame refs[3];
+      memset(refs, 0, sizeof(refs));
+      for (int k = 0; k < 3; ++k) {
+        const bool needed = (P->refs_used >> k) & 1;
+        const int s = ref_slot ? ref_slot[k] : -1;
+        if (s >= 0 && s < VP9HIP_POOL_SLOTS && dec->slots[s].used) {
+          refs[k] = dec->slots[s].f;
+          if (needed && (refs[k].width[0] != dec->params.ref_width[k] || refs[k].height[0] != dec->params.ref_height[k]))
+            DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: reference %d is %dx%d in the pool, %dx%d in the parameters", k,
+                     refs[k].width[0], refs[k].height[0], dec->params.ref_width[k], dec->params.ref_height[k]);
+          if (needed && (refs[k].hbd != dst->hbd || refs[k].bit_depth != dst->bit_depth))
+            DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: reference %d has another sample format", k);
+        } else if (needed) {
+          DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: reference %d is used by the frame but slot %d holds no frame", k, s);
+        } else {
+          refs[k] = *dst;  // placeholder, never read
+        }
+      }
+      DEC_CTX(dec, vp9hip_inter_pred_batch(dec->ctx, (const vp9hip_inter_task *)dec->d_inter.p, P->inter_class_count, refs, 3, dst));
+    }
+    if (dec->have_res) {
+      for (int p = 0; p < 3; ++p) {
+        const int w = dst->awidth[p], h = dst->aheight[p];
+        hipLaunchKernelGGL(residual_add_plane_kernel, dim3((w / 2 + 255) / 256, h), dim3(256), 0, st, (uint16_t *)dst->plane[p],
+                           dst->stride[p], (const int64_t *)dec->d_res[p].p, dec->res_stride[p], w, h, (1 << dst->bit_depth) - 1);
+      }
+      DEC_HIP(dec, hipGetLastError());
+    } else if (P->n_txb) {
+      if (!dec->have_coeffs) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: the frame has residuals but no coefficients were given");
+      DEC_CTX(dec, vp9hip_idct_add_batch(dec->ctx, (const vp9hip_txb *)dec->d_txb.p, P->txb_size_count, (const int32_t *)dec->d_coeffs.p, dst));
+    }
+  }
+
+  if ((phases & VP9HIP_PHASE_INTRA) && P->n_intra) {
+    const int32_t *coeffs = (dec->have_coeffs || dec->have_res) ? (const int32_t *)dec->d_coeffs.p : NULL;
+    if (dec->have_res) {
+      // residual of coded intra blocks: gather from the planes into the coefficient slots
+      vp9hip_intra_task *lists[2] = { (vp9hip_intra_task *)dec->d_isl_tasks.p, (vp9hip_intra_task *)dec->d_big_tasks.p };
+      const int counts[2] = { P->n_intra_island_tasks, P->n_intra_big_tasks };
+      for (int l = 0; l < 2; ++l) {
+        if (!counts[l]) continue;
+        hipLaunchKernelGGL(residual_gather_kernel, dim3(counts[l]), dim3(256), 0, st, lists[l], counts[l],
+                           (const int64_t *)dec->d_res[0].p, (const int64_t *)dec->d_res[1].p, (const int64_t *)dec->d_res[2].p,
+                           dec->res_stride[0], dec->res_stride[1], dec->res_stride[2], dst->aheight[0], dst->aheight[1],
+                           (int32_t *)dec->d_coeffs.p);
+        hipLaunchKernelGGL(mark_identity_kernel, dim3((counts[l] + 255) / 256), dim3(256), 0, st, lists[l], counts[l]);
+      }
+      DEC_HIP(dec, hipGetLastError());
+    }
+    if (P->n_islands)
+      DEC_CTX(dec, vp9hip_intra_pred_islands(dec->ctx, (const vp9hip_intra_task *)dec->d_isl_tasks.p,
+                                             (const vp9hip_intra_island *)dec->d_islands.p, P->n_islands,
+                                             (const int32_t *)dec->d_wave_off.p, coeffs, dst));
+    if (P->n_intra_big_tasks)
+      DEC_CTX(dec, vp9hip_intra_pred_waves(dec->ctx, (const vp9hip_intra_task *)dec->d_big_tasks.p, dec->big_wave_start,
+                                           P->n_big_waves, coeffs, dst));
+  }
+
+  if (phases & VP9HIP_PHASE_LF) {
+    if (!thresh) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: loop filter needs the threshold table");
+    if (h_lfm) {
+      int rc = dv_upload(dec, &dec->d_lfm, h_lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols);
+      if (rc) return rc;
+      DEC_HIP(dec, hipStreamSynchronize(st));  // h_lfm may be pageable and change after we return
+    } else if (!P->lfm) {
+      DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: no loop-filter masks (set params.build_lf_masks or pass them)");
+    }
+    DEC_CTX(dec, vp9hip_loop_filter_frame(dec->ctx, (const vp9hip_lfm *)dec->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
+                                          dec->params.ss_x ? 3 : 1));
+  }
+  DEC_CTX(dec, vp9hip_timer_end(dec->ctx, TIMER_RUN));
+  dec->timed = true;
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_decoder_sync(vp9hip_decoder *dec) {
+  if (!dec) return VP9HIP_EINVAL;
+  DEC_CTX(dec, vp9hip_sync(dec->ctx));
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_decoder_last_run_ms(vp9hip_decoder *dec, float *ms) {
+  if (!dec || !ms) return VP9HIP_EINVAL;
+  if (!dec->timed) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_last_run_ms: nothing was run");
+  DEC_CTX(dec, vp9hip_timer_read(dec->ctx, TIMER_RUN, ms));
+  return VP9HIP_OK;
+}
+
+extern "C" const vp9hip_packed *vp9hip_decoder_packed(const vp9hip_decoder *dec) {
+  return dec && dec->begun ? &dec->packed : NULL;
+}

@@ -494,7 +494,10 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
           if (!b->skip) {
             off = (uint32_t)(out->coeff_base[p] + run[p]);
             run[p] += nn;
-            if (coeffs && coeffs->eob[p]) eob = coeffs->eob[p][(size_t)y * coeffs->eob_stride[p] + x];
+            if (coeffs && coeffs->eob[p])
+              eob = coeffs->eob[p][(size_t)y * coeffs->eob_stride[p] + x];
+            else if (P->assume_coded)
+              eob = 1;
             if (eob < 0 || eob > nn) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: bad eob %d (block %d plane %d)", eob, i, p);
           }
           if (inter) {

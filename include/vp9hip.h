@@ -163,7 +163,8 @@ typedef struct vp9hip_intra_task {
   uint16_t x, y;
   uint8_t plane;
   uint8_t tx_size;
-  uint8_t tx_type; /* bit 7: lossless */
+  uint8_t tx_type; /* bit 7: lossless; bit 6: the N*N entries at coeff_off are the residual itself
+                      (raster, int32), no transform — residual-plane mode of vp9hip_decoder.h */
   uint8_t mode;    /* 0 DC 1 V 2 H 3 D45 4 D135 5 D117 6 D153 7 D207 8 D63 9 TM */
   uint16_t eob;
   uint8_t flags;   /* bit0 have_top, bit1 have_left, bit2 have_right, bit3 raw edges: read all 2*bs

@@ -1,0 +1,38 @@
+/*
+ * vp9hip_libvpx_shim.h — what shim/vp9hip_libvpx_shim.c exports besides the reference's own two
+ * symbols.  Include after the libvpx headers (it only forward-declares their structs).
+ *
+ * The two reference symbols keep the reference's prototypes and are declared by its caller
+ * (/root/reference/libvpx/vp9/decoder/vp9_decodeframe.c:2299-2302):
+ *   int wrap_cuda_inter_prediction(int n, double *gpu_copy, double *gpu_run, int *size_for_mb,
+ *                                  ModeInfoBuf *MiBuf, VP9_COMMON *cm, VP9Decoder *pbi,
+ *                                  int tile_rows, int tile_cols, tran_high_t *residuals);
+ *   int wrap_cuda_intra_prediction(double *gpu_copy, double *gpu_run, int *size_for_mb,
+ *                                  ModeInfoBuf *MiBuf, VP9_COMMON *cm, VP9Decoder *pbi,
+ *                                  int tile_rows, int tile_cols, frameBuf *frameBuffer);
+ * (/root/reference/vpx-master/cuda_extern_wrap.cpp:5-17).
+ */
+#ifndef VP9HIP_LIBVPX_SHIM_H_
+#define VP9HIP_LIBVPX_SHIM_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct VP9Decoder;
+struct frame_buffer; /* frameBuf, vpx-master/buffers_struct.h:9-15 */
+
+/* Coefficient mode: call once per frame right after initBuf() (vp9_decodeframe.c:2316), before the
+ * entropy loop advances frameBuffer->dqcoeff[].  From then on the wrappers run the inverse
+ * transforms on the GPU from frameBuffer->dqcoeff / plane_eob and ignore the residual planes, so the
+ * CPU transforms of phase B (vp9_decodeframe.c:2443-2534) can be removed.  NULL returns to the
+ * residual-plane mode. */
+void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_buffer *frameBuffer);
+
+/* Frees the GPU state kept for a decoder instance (call from vp9_decoder_remove). */
+void vp9hip_shim_release(struct VP9Decoder *pbi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP9HIP_LIBVPX_SHIM_H_ */

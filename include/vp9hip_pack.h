@@ -69,7 +69,10 @@ typedef struct vp9hip_frame_params {
    * from width/height; vp9_setup_scale_factors_for_frame, vp9_scale.c:46-77).  0 = unused. */
   int32_t ref_width[3], ref_height[3];
   int32_t build_lf_masks;   /* != 0: also build the loop-filter masks from the blocks */
-  int32_t reserved[3];
+  int32_t assume_coded;     /* != 0 and no eob planes given: every transform block of a non-skip block
+                               counts as coded (eob 1) — for the residual-plane mode, where adding the
+                               (zero) residual of an uncoded block changes nothing */
+  int32_t reserved[2];
 } vp9hip_frame_params;
 
 /* Where the coefficients of the frame are, in the reference's layout
@@ -123,9 +126,8 @@ void vp9hip_packer_destroy(vp9hip_packer *pk);
 const char *vp9hip_packer_error(const vp9hip_packer *pk);
 
 /* Packs one frame.  `out` points into the packer's arrays and stays valid until the next call.
- * coeffs may be NULL: then every non-skip transform block is emitted with eob 0 is NOT assumed —
- * instead NO residual records are produced (prediction only; the residual-plane mode of the
- * shim).  Returns VP9HIP_OK or VP9HIP_EINVAL / VP9HIP_ENOMEM. */
+ * coeffs may be NULL: every eob then reads as 0 (prediction only) unless params.assume_coded.
+ * Returns VP9HIP_OK or VP9HIP_EINVAL / VP9HIP_ENOMEM. */
 int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *params, const vp9hip_block *blocks,
                       int n_blocks, const vp9hip_coeff_layout *coeffs, vp9hip_packed *out);
 

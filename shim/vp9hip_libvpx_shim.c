@@ -1,0 +1,335 @@
+/*
+ * vp9hip_libvpx_shim.c — the reference's frame-level call surface on top of libvp9hip.so.
+ *
+ * Exports exactly the two symbols the reference's decoder links against
+ *   int wrap_cuda_inter_prediction(int n, double *gpu_copy, double *gpu_run, int *size_for_mb,
+ *         ModeInfoBuf *MiBuf, VP9_COMMON *cm, VP9Decoder *pbi, int tile_rows, int tile_cols,
+ *         tran_high_t *residuals);
+ *   int wrap_cuda_intra_prediction(double *gpu_copy, double *gpu_run, int *size_for_mb,
+ *         ModeInfoBuf *MiBuf, VP9_COMMON *cm, VP9Decoder *pbi, int tile_rows, int tile_cols,
+ *         frameBuf *frameBuffer);
+ * (/root/reference/vpx-master/cuda_extern_wrap.cpp:5-17; declared by the caller at
+ * libvpx/vp9/decoder/vp9_decodeframe.c:2299-2302, called at :2546 and :2564), with the
+ * reference's types (vpx-master/buffers_struct.h:9-57), so it replaces cuda_extern_wrap.cpp +
+ * inter_cuda_kernel.cu + intra_cuda_kernel.cu at link time and vpxdec needs no change.
+ *
+ * This file is C, compiled against the libvpx tree it is linked into (it needs the layouts of
+ * MODE_INFO / VP9_COMMON / VP9Decoder / YV12_BUFFER_CONFIG and that tree's vpx_config.h).  All it
+ * does is copy fields into the plain records of include/vp9hip_pack.h and call
+ * include/vp9hip_decoder.h; packing, transfers and kernels live in libvp9hip.so.
+ *
+ * Two residual modes:
+ *   - as called by the unchanged reference: the CPU transforms of its phase B already ran
+ *     (vp9_decodeframe.c:2443-2534) and `residuals` / frameBuffer->plane_residuals hold int64
+ *     residual planes -> they are added on the GPU (what the reference's kernels do,
+ *     vpx-master/inter_cuda_kernel.cu:821-829).  High-bitdepth frames only, like the reference.
+ *   - after vp9hip_shim_attach_frame_buffer(pbi, frameBuffer): the inverse transforms run on the
+ *     GPU from frameBuffer->dqcoeff / plane_eob and phase B can be deleted; `residuals` is ignored.
+ *
+ * Errors: a HIP / argument failure is reported through vpx_internal_error(&cm->error, ...), which
+ * longjmps to the decoder's trap when one is set (libvpx/vp9/decoder/vp9_decoder.c:458-466) —
+ * there is no CPU fallback.  Out-parameters *gpu_copy / *gpu_run are seconds, as in the
+ * reference (vpx-master/inter_cuda_kernel.cu:1069-1101).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "./vpx_config.h"
+#include "buffers_struct.h"
+#include "vp9/common/vp9_onyxc_int.h"
+#include "vp9/decoder/vp9_decoder.h"
+#include "vpx_ports/mem.h"
+
+#include "vp9hip_decoder.h"
+#include "vp9hip_libvpx_shim.h"
+
+#define SHIM_MAX_DECODERS 16
+/* pool slots: 0..2 = LAST/GOLDEN/ALTREF of the frame being decoded, 3 = the frame itself */
+#define SLOT_CUR 3
+
+typedef struct {
+  VP9Decoder *pbi;
+  vp9hip_decoder *dec;
+  const frameBuf *attached;     /* coefficient mode when non-NULL */
+  const tran_low_t *dq_start[3]; /* start of the per-plane coefficient arrays (attach time) */
+  vp9hip_block *blocks;
+  int blocks_cap;
+  int frame_open;               /* the inter wrapper began this frame and left it on the device */
+  unsigned int open_frame_no;
+  MODE_INFO **open_mi;
+} shim_state;
+
+static shim_state g_state[SHIM_MAX_DECODERS];
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static shim_state *state_of(VP9Decoder *pbi, VP9_COMMON *cm) {
+  int free_i = -1;
+  for (int i = 0; i < SHIM_MAX_DECODERS; ++i) {
+    if (g_state[i].pbi == pbi) return &g_state[i];
+    if (!g_state[i].pbi && free_i < 0) free_i = i;
+  }
+  if (free_i < 0) {
+    vpx_internal_error(&cm->error, VPX_CODEC_MEM_ERROR, "vp9hip shim: too many decoder instances");
+    return NULL; /* reached only when no setjmp trap is installed */
+  }
+  shim_state *s = &g_state[free_i];
+  memset(s, 0, sizeof(*s));
+  const char *dev = getenv("VP9HIP_DEVICE");
+  int rc = vp9hip_decoder_create(dev ? atoi(dev) : 0, &s->dec);
+  if (rc != VP9HIP_OK) {
+    vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: %s", vp9hip_last_error(NULL));
+    return NULL;
+  }
+  s->pbi = pbi;
+  return s;
+}
+
+void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_buffer *frameBuffer) {
+  shim_state *s = state_of(pbi, &pbi->common);
+  if (!s) return;
+  s->attached = frameBuffer;
+  if (frameBuffer)
+    for (int p = 0; p < 3; ++p) s->dq_start[p] = frameBuffer->dqcoeff[p];
+}
+
+void vp9hip_shim_release(struct VP9Decoder *pbi) {
+  for (int i = 0; i < SHIM_MAX_DECODERS; ++i)
+    if (g_state[i].pbi == pbi) {
+      vp9hip_decoder_destroy(g_state[i].dec);
+      free(g_state[i].blocks);
+      memset(&g_state[i], 0, sizeof(g_state[i]));
+    }
+}
+
+#define SHIM_CHECK(s, cm, expr)                                                                        \
+  do {                                                                                                 \
+    if ((expr) != VP9HIP_OK) {                                                                         \
+      (s)->frame_open = 0;                                                                             \
+      vpx_internal_error(&(cm)->error, VPX_CODEC_ERROR, "vp9hip shim: %s", vp9hip_decoder_error((s)->dec)); \
+      return -1; /* reached only when no setjmp trap is installed */                                   \
+    }                                                                                                  \
+  } while (0)
+
+static void host_frame(const YV12_BUFFER_CONFIG *b, int bit_depth, vp9hip_host_frame *h) {
+  const int hbd = (b->flags & YV12_FLAG_HIGHBITDEPTH) != 0;
+  memset(h, 0, sizeof(*h));
+  h->plane[0] = hbd ? (void *)CONVERT_TO_SHORTPTR(b->y_buffer) : (void *)b->y_buffer;
+  h->plane[1] = hbd ? (void *)CONVERT_TO_SHORTPTR(b->u_buffer) : (void *)b->u_buffer;
+  h->plane[2] = hbd ? (void *)CONVERT_TO_SHORTPTR(b->v_buffer) : (void *)b->v_buffer;
+  h->stride[0] = b->y_stride;
+  h->stride[1] = h->stride[2] = b->uv_stride;
+  h->width = b->y_crop_width;
+  h->height = b->y_crop_height;
+  h->ss_x = b->subsampling_x;
+  h->ss_y = b->subsampling_y;
+  h->bit_depth = bit_depth;
+  h->hbd = hbd;
+}
+
+/* mode_lf_lut + get_filter_level (libvpx/vp9/common/vp9_loopfilter.c:197-225) */
+static int filter_level_of(const VP9_COMMON *cm, const MODE_INFO *mi) {
+  static const int mode_lf_lut[MB_MODE_COUNT] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 1 };
+  return cm->lf_info.lvl[mi->segment_id][mi->ref_frame[0]][mode_lf_lut[mi->mode]];
+}
+
+static int gather_blocks(shim_state *s, VP9_COMMON *cm, const int *size_for_mb, const ModeInfoBuf *MiBuf) {
+  const int n_sb = ((cm->mi_rows + 7) >> 3) * ((cm->mi_cols + 7) >> 3);
+  int n = 0;
+  for (int i = 0; i < n_sb; ++i) n += size_for_mb[i];
+  if (n > s->blocks_cap) {
+    free(s->blocks);
+    s->blocks_cap = n + n / 4 + 64;
+    s->blocks = (vp9hip_block *)malloc(sizeof(vp9hip_block) * (size_t)s->blocks_cap);
+    if (!s->blocks) {
+      s->blocks_cap = 0;
+      vpx_internal_error(&cm->error, VPX_CODEC_MEM_ERROR, "vp9hip shim: out of memory");
+      return -1;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    const MODE_INFO *mi = MiBuf->mi[i];
+    vp9hip_block *b = &s->blocks[i];
+    memset(b, 0, sizeof(*b));
+    b->mi_row = (int16_t)MiBuf->mi_row[i];
+    b->mi_col = (int16_t)MiBuf->mi_col[i];
+    b->sb_type = (uint8_t)mi->sb_type;
+    b->tx_size = (uint8_t)mi->tx_size;
+    b->skip = (uint8_t)(mi->skip != 0);
+    b->ref_frame[0] = mi->ref_frame[0];
+    b->ref_frame[1] = mi->ref_frame[1];
+    b->filter_level = (uint8_t)filter_level_of(cm, mi);
+    if (is_inter_block(mi)) {
+      b->interp_filter = (uint8_t)mi->interp_filter;
+      for (int r = 0; r < 2; ++r) {
+        b->mv[r][0] = mi->mv[r].as_mv.row;
+        b->mv[r][1] = mi->mv[r].as_mv.col;
+        for (int k = 0; k < 4; ++k) {
+          b->sub_mv[k][r][0] = mi->bmi[k].as_mv[r].as_mv.row;
+          b->sub_mv[k][r][1] = mi->bmi[k].as_mv[r].as_mv.col;
+        }
+      }
+    } else {
+      b->mode = (uint8_t)mi->mode;
+      b->uv_mode = (uint8_t)mi->uv_mode;
+      for (int k = 0; k < 4; ++k) b->sub_mode[k] = (uint8_t)mi->bmi[k].as_mode;
+    }
+  }
+  return n;
+}
+
+static void frame_params(const VP9_COMMON *cm, const VP9Decoder *pbi, const YV12_BUFFER_CONFIG *cur, int coefficient_mode,
+                         vp9hip_frame_params *P) {
+  memset(P, 0, sizeof(*P));
+  P->width = cm->width;
+  P->height = cm->height;
+  P->ss_x = cm->subsampling_x;
+  P->ss_y = cm->subsampling_y;
+  P->bit_depth = (int)cm->bit_depth;
+  P->hbd = (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0;
+  P->lossless = pbi->mb.lossless;
+  P->log2_tile_cols = cm->log2_tile_cols;
+  P->assume_coded = !coefficient_mode;
+  if (cm->frame_type != KEY_FRAME && !cm->intra_only)
+    for (int k = 0; k < 3; ++k) {
+      const YV12_BUFFER_CONFIG *rb = cm->frame_refs[k].buf;
+      if (rb && rb->y_crop_width > 0) {
+        P->ref_width[k] = rb->y_crop_width;
+        P->ref_height[k] = rb->y_crop_height;
+      }
+    }
+}
+
+/* initBuf's plane pointers (libvpx/vp9/decoder/vp9_decodeframe.c:2242-2262): the residual planes
+ * mirror the frame buffer's layout sample for sample. */
+static void residual_planes(const YV12_BUFFER_CONFIG *cur, int byte_alignment, const tran_high_t *residuals,
+                            const int64_t *out[3], int32_t stride[3]) {
+  const int uv_border_h = cur->border >> cur->subsampling_y, uv_border_w = cur->border >> cur->subsampling_x;
+  const int align = byte_alignment == 0 ? 1 : byte_alignment;
+  const uint64_t yplane_size = (cur->y_height + 2 * cur->border) * (uint64_t)cur->y_stride + byte_alignment;
+  const uint64_t uvplane_size = (cur->uv_height + 2 * uv_border_h) * (uint64_t)cur->uv_stride + byte_alignment;
+  out[0] = (const int64_t *)yv12_align_addr(residuals + (cur->border * cur->y_stride) + cur->border, align);
+  out[1] = (const int64_t *)yv12_align_addr(residuals + yplane_size + (uv_border_h * cur->uv_stride) + uv_border_w, align);
+  out[2] = (const int64_t *)yv12_align_addr(
+      residuals + yplane_size + uvplane_size + (uv_border_h * cur->uv_stride) + uv_border_w, align);
+  stride[0] = cur->y_stride;
+  stride[1] = stride[2] = cur->uv_stride;
+}
+
+/* Pack + upload lists/coefficients (+ residual planes) for the current frame. */
+static int begin_frame(shim_state *s, VP9_COMMON *cm, VP9Decoder *pbi, int *size_for_mb, ModeInfoBuf *MiBuf,
+                       const tran_high_t *residuals, const frameBuf *fb_for_residuals) {
+  const YV12_BUFFER_CONFIG *cur = &cm->buffer_pool->frame_bufs[cm->new_fb_idx].buf;
+  vp9hip_frame_params P;
+  const int n = gather_blocks(s, cm, size_for_mb, MiBuf);
+  if (n < 0) return -1;
+  frame_params(cm, pbi, cur, s->attached != NULL, &P);
+  if (s->attached) {
+    vp9hip_coeff_layout L;
+    const int32_t *dq[3];
+    for (int p = 0; p < 3; ++p) {
+      L.eob[p] = s->attached->plane_eob[p];
+      L.eob_stride[p] = p ? cur->uv_stride : cur->y_stride;
+      dq[p] = (const int32_t *)s->dq_start[p];
+    }
+    if (sizeof(tran_low_t) != sizeof(int32_t)) {
+      vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: needs a CONFIG_VP9_HIGHBITDEPTH build (32-bit tran_low_t)");
+      return -1;
+    }
+    SHIM_CHECK(s, cm, vp9hip_decoder_begin_frame(s->dec, &P, s->blocks, n, &L, dq));
+  } else {
+    const int64_t *res[3];
+    int32_t rs[3];
+    SHIM_CHECK(s, cm, vp9hip_decoder_begin_frame(s->dec, &P, s->blocks, n, NULL, NULL));
+    if (fb_for_residuals) {
+      for (int p = 0; p < 3; ++p) res[p] = (const int64_t *)fb_for_residuals->plane_residuals[p];
+      rs[0] = cur->y_stride;
+      rs[1] = rs[2] = cur->uv_stride;
+    } else {
+      residual_planes(cur, cm->byte_alignment, residuals, res, rs);
+    }
+    SHIM_CHECK(s, cm, vp9hip_decoder_set_residual_planes(s->dec, res, rs));
+  }
+  return 0;
+}
+
+int wrap_cuda_inter_prediction(int n, double *gpu_copy, double *gpu_run, int *size_for_mb, ModeInfoBuf *MiBuf,
+                               VP9_COMMON *cm, VP9Decoder *pbi, int tile_rows, int tile_cols, tran_high_t *residuals) {
+  shim_state *s = state_of(pbi, cm);
+  const YV12_BUFFER_CONFIG *cur = &cm->buffer_pool->frame_bufs[cm->new_fb_idx].buf;
+  int ref_slot[3] = { -1, -1, -1 };
+  float ms = 0.f;
+  (void)n;
+  (void)tile_rows;
+  (void)tile_cols;
+  if (!s) return -1;
+  const double t0 = now_s();
+  s->frame_open = 0;
+  if (begin_frame(s, cm, pbi, size_for_mb, MiBuf, residuals, NULL)) return -1;
+  /* the reference re-sends its three references for every frame (inter_cuda_kernel.cu:1073-1079);
+   * only the ones the frame's blocks use travel here */
+  {
+    const vp9hip_packed *pk = vp9hip_decoder_packed(s->dec);
+    for (int k = 0; k < 3; ++k) {
+      vp9hip_host_frame h;
+      if (!((pk->refs_used >> k) & 1)) continue;
+      host_frame(cm->frame_refs[k].buf, (int)cm->bit_depth, &h);
+      SHIM_CHECK(s, cm, vp9hip_decoder_upload(s->dec, k, &h));
+      ref_slot[k] = k;
+    }
+  }
+  SHIM_CHECK(s, cm, vp9hip_decoder_alloc_slot(s->dec, SLOT_CUR, cm->width, cm->height, cm->subsampling_x, (int)cm->bit_depth,
+                                              (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0, 1));
+  const double t1 = now_s();
+  SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, VP9HIP_PHASE_INTER, ref_slot, SLOT_CUR, NULL, NULL));
+  SHIM_CHECK(s, cm, vp9hip_decoder_sync(s->dec));
+  SHIM_CHECK(s, cm, vp9hip_decoder_last_run_ms(s->dec, &ms));
+  /* the frame stays on the device: wrap_cuda_intra_prediction runs next on the same frame
+   * (vp9_decodeframe.c:2546-2564) and delivers it to the host */
+  s->frame_open = 1;
+  s->open_frame_no = cm->current_video_frame;
+  s->open_mi = MiBuf->mi;
+  if (gpu_copy) *gpu_copy = t1 - t0;
+  if (gpu_run) *gpu_run = (double)ms * 1e-3;
+  return 0;
+}
+
+int wrap_cuda_intra_prediction(double *gpu_copy, double *gpu_run, int *size_for_mb, ModeInfoBuf *MiBuf, VP9_COMMON *cm,
+                               VP9Decoder *pbi, int tile_rows, int tile_cols, frameBuf *frameBuffer) {
+  shim_state *s = state_of(pbi, cm);
+  const YV12_BUFFER_CONFIG *cur = &cm->buffer_pool->frame_bufs[cm->new_fb_idx].buf;
+  const int ref_slot[3] = { -1, -1, -1 };
+  vp9hip_host_frame h;
+  float ms = 0.f;
+  (void)tile_rows;
+  (void)tile_cols;
+  if (!s) return -1;
+  double t_copy = 0.0;
+  double t0 = now_s();
+  if (!(s->frame_open && s->open_frame_no == cm->current_video_frame && s->open_mi == MiBuf->mi)) {
+    /* key / intra-only frame path of the caller: the inter wrapper was not called */
+    if (begin_frame(s, cm, pbi, size_for_mb, MiBuf, NULL, frameBuffer)) return -1;
+    SHIM_CHECK(s, cm, vp9hip_decoder_alloc_slot(s->dec, SLOT_CUR, cm->width, cm->height, cm->subsampling_x,
+                                                (int)cm->bit_depth, (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0, 1));
+  }
+  s->frame_open = 0;
+  t_copy += now_s() - t0;
+  SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, VP9HIP_PHASE_INTRA, ref_slot, SLOT_CUR, NULL, NULL));
+  SHIM_CHECK(s, cm, vp9hip_decoder_sync(s->dec));
+  SHIM_CHECK(s, cm, vp9hip_decoder_last_run_ms(s->dec, &ms));
+  /* the reference's contract: the reconstructed frame is in the host buffer on return, because the
+   * CPU loop filter runs next (vp9_decodeframe.c:2585; intra_cuda_kernel.cu:1368) */
+  t0 = now_s();
+  host_frame(cur, (int)cm->bit_depth, &h);
+  SHIM_CHECK(s, cm, vp9hip_decoder_download(s->dec, SLOT_CUR, &h));
+  t_copy += now_s() - t0;
+  if (gpu_copy) *gpu_copy = t_copy;
+  if (gpu_run) *gpu_run = (double)ms * 1e-3;
+  return 0;
+}

@@ -6,10 +6,13 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
+SHIM_HEADER = "vp9hip_libvpx_shim.h"  # its symbols live in shim/build/libvp9hip_shim.so
+
+
+def declared_functions(only=None):
     names = set()
     for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
-        if not fn.endswith(".h"):
+        if not fn.endswith(".h") or (only is None and fn == SHIM_HEADER) or (only is not None and fn != only):
             continue
         text = open(os.path.join(ROOT, "include", fn)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -27,6 +30,22 @@ def test_library_exports_every_declared_symbol(hip):
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, f"declared in include/*.h but not exported by libvp9hip.so: {missing}"
     assert lib.vp9hip_abi_version() == 1
+
+
+def test_shim_exports_the_reference_call_surface():
+    """The two symbols the reference's decoder links against (vpx-master/cuda_extern_wrap.cpp:5-17)
+    + what include/vp9hip_libvpx_shim.h declares.  The shim is built against the reference tree, so
+    it only exists where that tree does (the built .so travels to the GPU box)."""
+    import pytest
+    so = os.path.join(ROOT, "shim", "build", "libvp9hip_shim.so")
+    if not os.path.exists(so):
+        pytest.skip("shim not built (reference tree absent)")
+    import subprocess
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    exported = {line.split()[-1] for line in syms.splitlines() if " T " in line}
+    want = declared_functions(only=SHIM_HEADER) | {"wrap_cuda_inter_prediction", "wrap_cuda_intra_prediction"}
+    assert "vp9hip_shim_attach_frame_buffer" in want
+    assert want <= exported, sorted(want - exported)
 
 
 def test_no_device_means_loud_failure(hip):
