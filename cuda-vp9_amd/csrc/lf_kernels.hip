@@ -191,15 +191,14 @@ __device__ __forceinline__ void lf_tile_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
-template <typename Pix, int N, bool WG_SYNC = true>
-__device__ __forceinline__ void lf_passes(Pix *tile, const unsigned *ctl, int x0, int y0, int pw, int ph, int mrows,
-                                          int sh) {
+// ---- vertical edges: lane = sample row; a 16-sample window slides along the row
+template <typename Pix, int N>
+__device__ __forceinline__ void lf_pass_v(Pix *tile, const unsigned *ctl, int y0, int ph, int mrows, int sh) {
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int n = N;
   constexpr int ncol = N / 8;
   const int lane = threadIdx.x & 63;
-  const unsigned *vE = ctl, *vI = ctl + 64, *hE = ctl + 128, *hI = ctl + 192;
-  // ---- vertical edges: lane = sample row; a 16-sample window slides along the row
+  const unsigned *vE = ctl, *vI = ctl + 64;
   if (lane < n && y0 + lane < ph && (lane >> 3) < mrows) {
     const int mr = lane >> 3;
     Pix *row = tile + (8 + lane) * TP;
@@ -228,9 +227,16 @@ __device__ __forceinline__ void lf_passes(Pix *tile, const unsigned *ctl, int x0
 #pragma unroll
     for (int k = 0; k < 8; ++k) row[ncol * 8 + k] = (Pix)w[k];
   }
-  lf_tile_sync<WG_SYNC>();
+}
 
-  // ---- horizontal edges: lane = sample column; the window slides down the column
+// ---- horizontal edges: lane = sample column; the window slides down the column
+template <typename Pix, int N>
+__device__ __forceinline__ void lf_pass_h(Pix *tile, const unsigned *ctl, int x0, int pw, int mrows, int sh) {
+  constexpr int TP = TileCfg<Pix>::TP;
+  constexpr int n = N;
+  constexpr int ncol = N / 8;
+  const int lane = threadIdx.x & 63;
+  const unsigned *hE = ctl + 128, *hI = ctl + 192;
   if (lane < n && x0 + lane < pw) {
     const int c = lane >> 3;  // mask column
     Pix *col = tile + 8 + lane;
@@ -258,8 +264,15 @@ __device__ __forceinline__ void lf_passes(Pix *tile, const unsigned *ctl, int x0
 #pragma unroll
     for (int k = 0; k < 8; ++k) col[(mrows * 8 + k) * TP] = (Pix)w[k];
   }
-  lf_tile_sync<WG_SYNC>();
+}
 
+template <typename Pix, int N, bool WG_SYNC = true>
+__device__ __forceinline__ void lf_passes(Pix *tile, const unsigned *ctl, int x0, int y0, int pw, int ph, int mrows,
+                                          int sh) {
+  lf_pass_v<Pix, N>(tile, ctl, y0, ph, mrows, sh);
+  lf_tile_sync<WG_SYNC>();
+  lf_pass_h<Pix, N>(tile, ctl, x0, pw, mrows, sh);
+  lf_tile_sync<WG_SYNC>();
 }
 
 // One (superblock, plane): N = 64 (luma) or 32 (4:2:0 chroma) samples per side.
@@ -470,16 +483,25 @@ __device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9h
 }
 
 
-// Two-wave form of the row walk: wave 0 filters superblock c while wave 1 writes back superblock
-// c-1, prefetches superblock c+1 (interior, mask record, rows above after the progress wait) into
-// the other tile buffer.  Wave 0 itself stores the 8 hand-off rows and publishes the progress as
-// soon as its passes are done, so the row below is not delayed by the pipelining.  (Moving the
-// hand-off to wave 1 was measured: no gain, 913 vs 898 us per 1440p frame — the passes, ~19k
-// cycles per luma superblock, are the critical path, not the stores.)
+// Two-wave form of the row walk: wave 0 filters, wave 1 moves data.  Per superblock c:
+//   phase A   wave 0: vertical pass of c, then the 8x8 corner it completed (bottom rows of the
+//             PREVIOUS superblock's last 8 columns) goes out write-through and v-progress = c+1.
+//             wave 1: bulk write-back of c-1, then waits for the row above and brings its bottom
+//             8 rows into tile rows 0..7 (which the vertical pass does not touch).
+//   phase B   wave 0: horizontal pass of c, hand-off rows out write-through, h-progress = c+1.
+//             wave 1: interior of c+1 global -> registers.
+//   phase C   wave 0: right strip -> left strip of the other buffer; wave 1: registers -> LDS.
+// The rows above superblock c are final once the row above has done the horizontal pass of ITS
+// superblock c (columns 0..55 of c) and the vertical pass of its superblock c+1 (the last 8
+// columns: that pass's first edge reaches 8 samples back) — (r-1,c+1)'s horizontal pass never
+// touches columns left of 64(c+1).  Waiting only for that, and only before the horizontal pass,
+// halves the lag between superblock rows from two superblock steps to one
+// (critical path cols + rows instead of cols + 2*rows).
 template <typename Pix, int N>
 __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const vp9hip_lfm *__restrict__ lfms,
                                              int sb_cols, int sr, int pl, const LfThreshDev &th, const FrameDev &f,
-                                             int mi_rows, int *progress_prev, int *progress_mine, int *err) {
+                                             int mi_rows, int *vprog_prev, int *hprog_prev, int *vprog_mine,
+                                             int *hprog_mine, int *err) {
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int PPD = 4 / sizeof(Pix);
   constexpr int n = N;
@@ -500,10 +522,9 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   const int ncols = min(sb_cols, (pw + n - 1) / n);  // superblocks of this plane row
   bool dead = false;
 
-  // what wave 1 carries from phase 1 (global loads) to phase 2 (LDS stores)
-  unsigned reg[KI], above[KA];
+  unsigned reg[KI];  // wave 1: interior of the next superblock between phase B and phase C
 
-  auto load_sb = [&](int sc) {  // wave 1: global -> registers (waits for the row above)
+  auto load_interior = [&](int sc) {  // wave 1: global -> registers (private rows: plain loads)
     const int x0 = sc * n;
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
@@ -513,18 +534,36 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       reg[k] = 0;
       if (i < n * DPR && gx < pw && gy < ph) reg[k] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
     }
+  };
+  auto store_interior = [&](int sc) {  // wave 1: registers -> LDS tile + controls of superblock sc
+    unsigned *t32 = (unsigned *)(tiles + (sc & 1) * TILE);
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int i = lane + 64 * k;
+      const int r = i / DPR, d = i - r * DPR;
+      if (i < n * DPR) t32[(8 + r) * TPD + 8 / PPD + d] = reg[k];
+    }
+    lf_controls<N>(ctls + (sc & 1) * 256, lfms[sr * sb_cols + sc], pl, mi_row, rows_mi, mi_rows, th);
+  };
+  auto wait_for = [&](int *ctr, int need) {
+    int spins = 0;
+    while (!dead && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > LF_SPIN_LIMIT) {
+        if (lane == 0) atomicExch(err, 1);
+        dead = true;
+      }
+    }
+  };
+  auto fetch_above = [&](int sc) {  // wave 1: bottom 8 rows of the row above -> tile rows 0..7
+    unsigned *t32 = (unsigned *)(tiles + (sc & 1) * TILE);
+    const int x0 = sc * n;
+    unsigned above[KA];
 #pragma unroll
     for (int k = 0; k < KA; ++k) above[k] = 0;
     if (sr > 0) {
-      const int need = min(sc + 2, sb_cols);
-      int spins = 0;
-      while (!dead && __hip_atomic_load(progress_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > LF_SPIN_LIMIT) {
-          if (lane == 0) atomicExch(err, 1);
-          dead = true;
-        }
-      }
+      wait_for(hprog_prev, sc + 1);                      // its horizontal pass of sc
+      if (sc + 1 < ncols) wait_for(vprog_prev, sc + 2);  // its vertical pass of sc+1 (last 8 columns)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int k = 0; k < KA; ++k) {
@@ -534,22 +573,12 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         if (i < 8 * DPR && gx < pw) above[k] = ld_sc1((const unsigned *)(plane + (size_t)gy * stride + gx));
       }
     }
-  };
-  auto store_sb = [&](int sc) {  // wave 1: registers -> LDS tile + controls of superblock sc
-    unsigned *t32 = (unsigned *)(tiles + (sc & 1) * TILE);
-#pragma unroll
-    for (int k = 0; k < KI; ++k) {
-      const int i = lane + 64 * k;
-      const int r = i / DPR, d = i - r * DPR;
-      if (i < n * DPR) t32[(8 + r) * TPD + 8 / PPD + d] = reg[k];
-    }
 #pragma unroll
     for (int k = 0; k < KA; ++k) {
       const int i = lane + 64 * k;
       const int r = i / DPR, d = i - r * DPR;
       if (i < 8 * DPR) t32[r * TPD + 8 / PPD + d] = above[k];
     }
-    lf_controls<N>(ctls + (sc & 1) * 256, lfms[sr * sb_cols + sc], pl, mi_row, rows_mi, mi_rows, th);
   };
   auto bulk_writeback = [&](int sc) {  // wave 1: everything of superblock sc except the hand-off rows
     const int x0 = sc * n;
@@ -569,50 +598,62 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         *gp = t32[r * TPD + d];
     }
   };
+  // wave 0: tile rows n..n+7 (the bottom 8 rows of this superblock row), tile columns [c0, c1), out
+  // write-through and drained
+  auto handoff = [&](const unsigned *t32, int x0, int c0, int c1) {
+    constexpr int wd = (n + 8) / PPD;
+    for (int i = lane; i < 8 * wd; i += 64) {
+      const int r = n + i / wd, d = i % wd;
+      const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
+      if (d * PPD < c0 || d * PPD >= c1 || gx < 0 || gx >= pw || gy >= ph) continue;
+      st_sc1((unsigned *)(plane + (size_t)gy * stride + gx), t32[r * TPD + d]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
 
-  // prologue: superblock 0 into buffer 0
+  // prologue: interior of superblock 0 into buffer 0
   if (wave == 1) {
-    load_sb(0);
-    store_sb(0);
+    load_interior(0);
+    store_interior(0);
   }
   __syncthreads();
   for (int sc = 0; sc < ncols; ++sc) {
     const int x0 = sc * n;
     const bool last = sc == ncols - 1;
     Pix *tile = tiles + (sc & 1) * TILE;
-    // ---- phase 1
+    unsigned *t32 = (unsigned *)tile;
+    const unsigned *ctl = ctls + (sc & 1) * 256;
+    // ---- phase A
     if (wave == 0) {
-      lf_passes<Pix, N, false>(tile, ctls + (sc & 1) * 256, x0, y0, pw, ph, mrows, sh);
-      // hand-off rows (tile rows n .. n+7) out write-through, then publish: done before the
-      // workgroup barrier so that the row below never waits on this row's prefetch wave
-      unsigned *t32 = (unsigned *)tile;
-      const int wcols = last ? n + 8 : n;
-      constexpr int wd = (n + 8) / PPD;
-      for (int i = lane; i < 8 * wd; i += 64) {
-        const int r = n + i / wd, d = i % wd;
-        const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
-        if (d * PPD >= wcols || gx < 0 || gx >= pw || gy >= ph) continue;
-        st_sc1((unsigned *)(plane + (size_t)gy * stride + gx), t32[r * TPD + d]);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        __hip_atomic_store(progress_mine, last ? sb_cols : sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lf_pass_v<Pix, N>(tile, ctl, y0, ph, mrows, sh);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      if (sc > 0) handoff(t32, x0, 0, 8);  // the corner this pass completed
+      if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (sc > 0) bulk_writeback(sc - 1);
-      if (!last) load_sb(sc + 1);
+      fetch_above(sc);
     }
     __syncthreads();
-    // ---- phase 2
+    // ---- phase B
+    if (wave == 0) {
+      lf_pass_h<Pix, N>(tile, ctl, x0, pw, mrows, sh);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      handoff(t32, x0, 8, last ? n + 8 : n);
+      if (lane == 0) __hip_atomic_store(hprog_mine, last ? sb_cols : sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (!last) load_interior(sc + 1);
+    }
+    __syncthreads();
+    // ---- phase C
     if (wave == 0) {
       // the right strip becomes the left strip of the next superblock (other buffer)
       if (!last && lane < n) {
-        const unsigned *t32 = (const unsigned *)tile;
         unsigned *nt32 = (unsigned *)(tiles + ((sc + 1) & 1) * TILE);
 #pragma unroll
         for (int d = 0; d < 8 / PPD; ++d) nt32[(8 + lane) * TPD + d] = t32[(8 + lane) * TPD + n / PPD + d];
       }
     } else {
-      if (!last) store_sb(sc + 1);
+      if (!last) store_interior(sc + 1);
     }
     __syncthreads();
   }
@@ -626,12 +667,14 @@ __global__ __launch_bounds__(128) void lf_rows2_kernel(const vp9hip_lfm *__restr
   __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
   __shared__ unsigned ctls[2 * 256];
   const int sr = blockIdx.x, pl = blockIdx.y;
-  int *prev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
-  int *mine = progress + pl * sb_rows + sr;
+  // progress[0 .. 3*sb_rows): horizontal-pass counters; [3*sb_rows .. 6*sb_rows): vertical-pass counters
+  int *hprev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
+  int *hmine = progress + pl * sb_rows + sr;
+  int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
   if (pl == 0)
-    lf_row2_body<Pix, 64>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
+    lf_row2_body<Pix, 64>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err);
   else
-    lf_row2_body<Pix, 32>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
+    lf_row2_body<Pix, 32>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err);
 }
 
 template <typename Pix>
@@ -673,10 +716,10 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
   }
   if (mode != 0) {
     // one launch: a workgroup per (superblock row, plane), progress counters in context scratch
-    const size_t need = (size_t)(3 * sb_rows + 1) * sizeof(int);
+    const size_t need = (size_t)(6 * sb_rows + 1) * sizeof(int);
     int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
     if (rc) return rc;
-    int *progress = (int *)ctx->scratch, *err = progress + 3 * sb_rows;
+    int *progress = (int *)ctx->scratch, *err = progress + 6 * sb_rows;
     VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
     ctx->lf_err_flag = err;
     if (mode == 2) {

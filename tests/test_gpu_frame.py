@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
     (320, 192, 10, dict(compound_frac=0.5)),
     (256, 128, 8, dict(all_intra=True)),
     (1920, 1080, 8, {}),
+    # BASELINE.json configs[3]: 2160p 8-bit all-inter, high motion (stresses the convolve)
+    (3840, 2160, 8, dict(intra_frac=0.0, compound_frac=0.3, skip_frac=0.6)),
+    # BASELINE.json configs[4]: 1080p 10-bit (highbd transform / convolve path)
+    (1920, 1080, 10, {}),
 ])
 def test_frame_pipeline_matches_oracle(hip, oracle, W, H, bd, kw):
     import cuda_vp9_amd.workload as workload
