@@ -483,14 +483,17 @@ __device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9h
 }
 
 
-// Two-wave form of the row walk: wave 0 filters, wave 1 moves data.  Per superblock c:
-//   phase A   wave 0: vertical pass of c, then the 8x8 corner it completed (bottom rows of the
-//             PREVIOUS superblock's last 8 columns) goes out write-through and v-progress = c+1.
+// Three-wave form of the row walk: wave 0 filters, wave 1 moves data in, wave 2 hands rows to the
+// row below.  Per superblock c:
+//   phase A   wave 0: vertical pass of c, LDS flag.
 //             wave 1: bulk write-back of c-1, then waits for the row above and brings its bottom
 //             8 rows into tile rows 0..7 (which the vertical pass does not touch).
-//   phase B   wave 0: horizontal pass of c, hand-off rows out write-through, h-progress = c+1.
-//             wave 1: interior of c+1 global -> registers.
-//   phase C   wave 0: right strip -> left strip of the other buffer; wave 1: registers -> LDS.
+//             wave 2: on the flag, the 8x8 corner that pass completed (bottom rows of the PREVIOUS
+//             superblock's last 8 columns) goes out write-through; drained; v-progress = c+1.
+//   phase B   wave 0: horizontal pass of c, LDS flag, right strip -> left strip of the other buffer.
+//             wave 1: interior + controls of c+1 into the other buffer.
+//             wave 2: on the flag, the hand-off rows out write-through; drained; h-progress = c+1.
+// Wave 0 never waits for a store to drain (two drains per superblock were ~15 % of its time).
 // The rows above superblock c are final once the row above has done the horizontal pass of ITS
 // superblock c (columns 0..55 of c) and the vertical pass of its superblock c+1 (the last 8
 // columns: that pass's first edge reaches 8 samples back) — (r-1,c+1)'s horizontal pass never
@@ -501,7 +504,7 @@ template <typename Pix, int N>
 __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const vp9hip_lfm *__restrict__ lfms,
                                              int sb_cols, int sr, int pl, const LfThreshDev &th, const FrameDev &f,
                                              int mi_rows, int *vprog_prev, int *hprog_prev, int *vprog_mine,
-                                             int *hprog_mine, int *err) {
+                                             int *hprog_mine, int *err, volatile unsigned *flags) {
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int PPD = 4 / sizeof(Pix);
   constexpr int n = N;
@@ -611,11 +614,20 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
+  // wave 2 (publisher): waits for wave 0's LDS flag, sends the rows out and publishes the progress
+  // once they have drained — wave 0 never waits for a store.  flags[0]: vertical passes done,
+  // flags[1]: horizontal passes done (monotonic, written by wave 0 lane 0 after its LDS fence).
+  auto wait_flag = [&](volatile unsigned *flag, unsigned need) {
+    while (*flag < need) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+
   // prologue: interior of superblock 0 into buffer 0
   if (wave == 1) {
     load_interior(0);
     store_interior(0);
   }
+  if (threadIdx.x == 0) flags[0] = flags[1] = 0;
   __syncthreads();
   for (int sc = 0; sc < ncols; ++sc) {
     const int x0 = sc * n;
@@ -626,34 +638,38 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     // ---- phase A
     if (wave == 0) {
       lf_pass_v<Pix, N>(tile, ctl, y0, ph, mrows, sh);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      if (sc > 0) handoff(t32, x0, 0, 8);  // the corner this pass completed
-      if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) flags[0] = sc + 1;
+    } else if (wave == 1) {
       if (sc > 0) bulk_writeback(sc - 1);
       fetch_above(sc);
+    } else {
+      wait_flag(&flags[0], sc + 1);
+      if (sc > 0) handoff(t32, x0, 0, 8);  // the corner the vertical pass completed (drained)
+      if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    // ---- phase B
+    // ---- phase B + C: wave 0 filters and moves the strip, wave 1 prefetches, wave 2 publishes
     if (wave == 0) {
       lf_pass_h<Pix, N>(tile, ctl, x0, pw, mrows, sh);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      handoff(t32, x0, 8, last ? n + 8 : n);
-      if (lane == 0) __hip_atomic_store(hprog_mine, last ? sb_cols : sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      if (!last) load_interior(sc + 1);
-    }
-    __syncthreads();
-    // ---- phase C
-    if (wave == 0) {
-      // the right strip becomes the left strip of the next superblock (other buffer)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) flags[1] = sc + 1;
+      // the right strip becomes the left strip of the next superblock (other buffer; its rows
+      // 8.. columns 0..7 are not touched by wave 1's interior store)
       if (!last && lane < n) {
         unsigned *nt32 = (unsigned *)(tiles + ((sc + 1) & 1) * TILE);
 #pragma unroll
         for (int d = 0; d < 8 / PPD; ++d) nt32[(8 + lane) * TPD + d] = t32[(8 + lane) * TPD + n / PPD + d];
       }
+    } else if (wave == 1) {
+      if (!last) {
+        load_interior(sc + 1);
+        store_interior(sc + 1);
+      }
     } else {
-      if (!last) store_interior(sc + 1);
+      wait_flag(&flags[1], sc + 1);
+      handoff(t32, x0, 8, last ? n + 8 : n);
+      if (lane == 0) __hip_atomic_store(hprog_mine, last ? sb_cols : sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
@@ -661,20 +677,21 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
 }
 
 template <typename Pix>
-__global__ __launch_bounds__(128) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
+__global__ __launch_bounds__(192) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                                        LfThreshDev th, FrameDev f, int mi_rows, int *progress,
                                                        int *err) {
   __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
   __shared__ unsigned ctls[2 * 256];
+  __shared__ unsigned flags[2];
   const int sr = blockIdx.x, pl = blockIdx.y;
   // progress[0 .. 3*sb_rows): horizontal-pass counters; [3*sb_rows .. 6*sb_rows): vertical-pass counters
   int *hprev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
   int *hmine = progress + pl * sb_rows + sr;
   int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
   if (pl == 0)
-    lf_row2_body<Pix, 64>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err);
+    lf_row2_body<Pix, 64>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags);
   else
-    lf_row2_body<Pix, 32>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err);
+    lf_row2_body<Pix, 32>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags);
 }
 
 template <typename Pix>
@@ -724,10 +741,10 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
     ctx->lf_err_flag = err;
     if (mode == 2) {
       if (frame->hbd)
-        hipLaunchKernelGGL(lf_rows2_kernel<uint16_t>, dim3(sb_rows, planes), dim3(128), 0, ctx->stream, d_lfm, sb_cols,
+        hipLaunchKernelGGL(lf_rows2_kernel<uint16_t>, dim3(sb_rows, planes), dim3(192), 0, ctx->stream, d_lfm, sb_cols,
                            sb_rows, th, f, mi_rows, progress, err);
       else
-        hipLaunchKernelGGL(lf_rows2_kernel<uint8_t>, dim3(sb_rows, planes), dim3(128), 0, ctx->stream, d_lfm, sb_cols,
+        hipLaunchKernelGGL(lf_rows2_kernel<uint8_t>, dim3(sb_rows, planes), dim3(192), 0, ctx->stream, d_lfm, sb_cols,
                            sb_rows, th, f, mi_rows, progress, err);
     } else if (frame->hbd)
       hipLaunchKernelGGL(lf_rows_kernel<uint16_t>, dim3(sb_rows, planes), dim3(64), 0, ctx->stream, d_lfm, sb_cols,
