@@ -310,21 +310,46 @@ struct FastPlan {
   int task_count[5];
 };
 
+// XCD-aware order inside a class.  Workgroup b runs on XCD b % 8 (round-robin dispatch; an affinity
+// assumption used for speed only) and each XCD has its own L2.  A class's tasks are in decode
+// (superblock-raster) order, so handing XCD x the x-th contiguous eighth of every class makes
+// each XCD work on one horizontal band of the frame across all classes: overlapping windows of
+// neighbouring tiles and the band of each reference it reads stay in that XCD's 4 MiB L2 instead
+// of being fetched once per XCD (PMC, 1440p frame: FETCH_SIZE 99 MB -> 25 MB, L2 hit rate
+// 37 % -> 86 %; profiles/r01_pmc_s2a.json vs r01_pmc_s2b.json).
+__device__ __forceinline__ int xcd_order(int b, int s0, int s1) {
+  const int x = b & 7;
+  int prefix = 0, first_x = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int first = s0 + ((j - s0) & 7);  // first workgroup of [s0, s1) on XCD j
+    const int cnt = first < s1 ? (s1 - first + 7) >> 3 : 0;
+    if (j < x) prefix += cnt;
+    if (j == x) first_x = first;
+  }
+  return prefix + ((b - first_x) >> 3);
+}
+
 __global__ __launch_bounds__(FAST_THREADS) void inter_fast_kernel(const vp9hip_inter_task *__restrict__ tasks,
                                                                   FastPlan plan, RefSet refs, FrameDev dstf,
                                                                   const unsigned *__restrict__ taps) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[FAST_LDS];
   const int b = blockIdx.x;
   if (b < plan.wg_start[1])
-    inter_fast_body<4>(lds, b - plan.wg_start[0], tasks + plan.task_start[0], plan.task_count[0], refs, dstf, taps);
+    inter_fast_body<4>(lds, xcd_order(b, plan.wg_start[0], plan.wg_start[1]), tasks + plan.task_start[0],
+                       plan.task_count[0], refs, dstf, taps);
   else if (b < plan.wg_start[2])
-    inter_fast_body<8>(lds, b - plan.wg_start[1], tasks + plan.task_start[1], plan.task_count[1], refs, dstf, taps);
+    inter_fast_body<8>(lds, xcd_order(b, plan.wg_start[1], plan.wg_start[2]), tasks + plan.task_start[1],
+                       plan.task_count[1], refs, dstf, taps);
   else if (b < plan.wg_start[3])
-    inter_fast_body<16>(lds, b - plan.wg_start[2], tasks + plan.task_start[2], plan.task_count[2], refs, dstf, taps);
+    inter_fast_body<16>(lds, xcd_order(b, plan.wg_start[2], plan.wg_start[3]), tasks + plan.task_start[2],
+                        plan.task_count[2], refs, dstf, taps);
   else if (b < plan.wg_start[4])
-    inter_fast_body<32>(lds, b - plan.wg_start[3], tasks + plan.task_start[3], plan.task_count[3], refs, dstf, taps);
+    inter_fast_body<32>(lds, xcd_order(b, plan.wg_start[3], plan.wg_start[4]), tasks + plan.task_start[3],
+                        plan.task_count[3], refs, dstf, taps);
   else
-    inter_fast_body<64>(lds, b - plan.wg_start[4], tasks + plan.task_start[4], plan.task_count[4], refs, dstf, taps);
+    inter_fast_body<64>(lds, xcd_order(b, plan.wg_start[4], plan.wg_start[5]), tasks + plan.task_start[4],
+                        plan.task_count[4], refs, dstf, taps);
 }
 
 template <int W>
