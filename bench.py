@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-phase-timers", action="store_true")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="extra leg: this many independent streams in flight on the GPU (0 = skip); reported "
+                         "under multi_stream, never as `value`")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +107,35 @@ def main():
             phase_ms[ph] += ctx.timer_read(4 * (i % max_timed) + k)
     phase_ms = {ph: (v / n_timed if n_timed else None) for ph, v in phase_ms.items()}
 
+    # ---- extra leg: several independent streams in flight on one GPU (one context = one HIP stream
+    # each).  The loop filter keeps 69 of 256 CUs busy, so frames of other streams fit beside it.
+    multi = None
+    if args.streams > 1:
+        ctxs = [pkg.Context(local_rank) for _ in range(args.streams)]
+        mjobs = [[pipeline.FrameJob(c, wl) for wl in wls[:2]] for c in ctxs]
+        for w in range(3):
+            for js in mjobs:
+                js[w % len(js)].run()
+        for c in ctxs:
+            c.sync()
+        barrier()
+        n_rounds = max(10, args.steps // 4)
+        tm0 = time.perf_counter()
+        for i in range(n_rounds):
+            for js in mjobs:
+                js[i % len(js)].run()
+        for c in ctxs:
+            c.sync()
+        barrier()
+        tm = time.perf_counter() - tm0
+        multi = {"streams": args.streams, "frames": n_rounds * args.streams,
+                 "frames_per_s": round(n_rounds * args.streams / tm, 1)}
+        for js in mjobs:
+            for j in js:
+                j.free()
+        for c in ctxs:
+            c.close()
+
     # correctness of what was timed: frame 0 against the oracle (rank 0 only; small CPU cost)
     md5_match = None
     cpu_baseline = None
@@ -127,6 +159,9 @@ def main():
     import cuda_vp9_amd.batch as batch
     frames_total, _, t_max = batch.reduce_stats(dist, args.steps, 0.0, elapsed,
                                                 device=torch.device("cuda", local_rank))
+    if multi is not None:
+        m_total, _, _ = batch.reduce_stats(dist, multi["frames_per_s"], 0.0, 0.0, device=torch.device("cuda", local_rank))
+        multi["frames_per_s_all_gpus"] = round(m_total, 1)
 
     if rank == 0:
         kernels = {}
@@ -141,8 +176,25 @@ def main():
         roofline = None
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])
+            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+            # runs of the same workload, tools/pmc_collect.sh; FETCH_SIZE doubled as calibrated on gfx950 with
+            # tools/fetch_calibrate.hip) — measured offline, committed under profiles/
+            traffic, pmc = None, {}
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
+                e = pmc.get(dom)
+                if e and args.width == 2560 and args.height == 1440 and args.bit_depth == 8:
+                    traffic = int(e["hbm_read_bytes_gfx950_x2"] + e["hbm_write_bytes"])
+            except (OSError, KeyError, ValueError):
+                pass
+            for k, v in kernels.items():
+                e = pmc.get(k)
+                if e and traffic is not None:
+                    v["hbm_traffic_bytes_pmc"] = int(e["hbm_read_bytes_gfx950_x2"] + e["hbm_write_bytes"])
+                    if "lds_bank_conflict_frac" in e:
+                        v["lds_bank_conflict_frac_pmc"] = e["lds_bank_conflict_frac"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None}
+                        "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic}
         out = {
             "metric": "decoded frames/sec (block-reconstruction path: inter+idct+intra+loop filter), 1440p VP9 8-bit",
             "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -156,7 +208,7 @@ def main():
                                    f"{args.frames} distinct frames resident in HBM, one stream per GPU",
                        "parallelism": f"streams{world}"},
             "md5_match_vs_oracle": md5_match,
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_baseline, "multi_stream": multi,
         }
         print(json.dumps(out))
     if dist is not None:
