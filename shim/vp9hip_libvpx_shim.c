@@ -272,6 +272,7 @@ int wrap_cuda_inter_prediction(int n, double *gpu_copy, double *gpu_run, int *si
   const double t0 = now_s();
   s->frame_open = 0;
   if (begin_frame(s, cm, pbi, size_for_mb, MiBuf, residuals, NULL)) return -1;
+  const double t_begin = now_s();
   /* the reference re-sends its three references for every frame (inter_cuda_kernel.cu:1073-1079);
    * only the ones the frame's blocks use travel here */
   {
@@ -287,6 +288,9 @@ int wrap_cuda_inter_prediction(int n, double *gpu_copy, double *gpu_run, int *si
   SHIM_CHECK(s, cm, vp9hip_decoder_alloc_slot(s->dec, SLOT_CUR, cm->width, cm->height, cm->subsampling_x, (int)cm->bit_depth,
                                               (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0, 1));
   const double t1 = now_s();
+  if (getenv("VP9HIP_SHIM_TRACE"))
+    fprintf(stderr, "vp9hip shim: inter wrapper: pack + lists + coefficients %.2f ms, references + frame slot %.2f ms\n",
+            (t_begin - t0) * 1e3, (t1 - t_begin) * 1e3);
   SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, VP9HIP_PHASE_INTER, ref_slot, SLOT_CUR, NULL, NULL));
   SHIM_CHECK(s, cm, vp9hip_decoder_sync(s->dec));
   SHIM_CHECK(s, cm, vp9hip_decoder_last_run_ms(s->dec, &ms));
