@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-phase-timers", action="store_true")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="extra leg: this many independent streams in flight on the GPU (0 = skip); reported "
                          "under multi_stream, never as `value`")
     args = ap.parse_args()
@@ -130,6 +130,7 @@ def main():
         tm = time.perf_counter() - tm0
         multi = {"streams": args.streams, "frames": n_rounds * args.streams,
                  "frames_per_s": round(n_rounds * args.streams / tm, 1)}
+        multi_got = [js[0].download() for js in mjobs] if rank == 0 else None  # checked against the oracle below
         for js in mjobs:
             for j in js:
                 j.free()
@@ -145,6 +146,9 @@ def main():
         got = jobs[0].download()
         exp, _ = frame_check.oracle_frame(oracle, wls[0])
         md5_match = frame_check.frame_md5(got, wls[0]) == frame_check.frame_md5(exp, wls[0])
+        if multi is not None:
+            multi["md5_match_vs_oracle"] = all(frame_check.frame_md5(g_, wls[0]) == frame_check.frame_md5(exp, wls[0])
+                                               for g_ in multi_got)
         if world == 1 and not args.no_cpu_baseline:
             n, t_cpu = 0, 0.0
             while t_cpu < args.cpu_seconds or n < 2:
