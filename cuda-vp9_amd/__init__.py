@@ -86,6 +86,15 @@ class Packed(ctypes.Structure):
                 ("refs_used", ctypes.c_uint32)]
 
 
+class HostFrame(ctypes.Structure):
+    _fields_ = [("plane", ctypes.c_void_p * 3), ("stride", ctypes.c_int32 * 3), ("width", ctypes.c_int32),
+                ("height", ctypes.c_int32), ("ss_x", ctypes.c_int32), ("ss_y", ctypes.c_int32),
+                ("bit_depth", ctypes.c_int32), ("hbd", ctypes.c_int32)]
+
+
+PHASE_INTER, PHASE_INTRA, PHASE_LF = 1, 2, 4
+
+
 class LfThresh(ctypes.Structure):
     _fields_ = [("mblim", ctypes.c_uint8 * 64), ("lim", ctypes.c_uint8 * 64),
                 ("hev_thr", ctypes.c_uint8 * 64)]
@@ -136,6 +145,93 @@ def _arr(ptr, n, dtype):
         return np.zeros(0, dtype)
     buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class Decoder:
+    """vp9hip_decoder (include/vp9hip_decoder.h): frame pool + transfers + phase sequencing."""
+
+    def __init__(self, device=0):
+        L = lib()
+        vp = ctypes.c_void_p
+        L.vp9hip_decoder_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.vp9hip_decoder_destroy.argtypes = [vp]
+        L.vp9hip_decoder_destroy.restype = None
+        L.vp9hip_decoder_error.argtypes = [vp]
+        L.vp9hip_decoder_error.restype = ctypes.c_char_p
+        L.vp9hip_decoder_upload.argtypes = [vp, ctypes.c_int, ctypes.POINTER(HostFrame)]
+        L.vp9hip_decoder_download.argtypes = [vp, ctypes.c_int, ctypes.POINTER(HostFrame)]
+        L.vp9hip_decoder_alloc_slot.argtypes = [vp] + [ctypes.c_int] * 7
+        L.vp9hip_decoder_begin_frame.argtypes = [vp, ctypes.POINTER(FrameParams), vp, ctypes.c_int,
+                                                 ctypes.POINTER(CoeffLayout), ctypes.POINTER(vp * 3)]
+        L.vp9hip_decoder_run.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int * 3), ctypes.c_int, vp, vp]
+        L.vp9hip_decoder_sync.argtypes = [vp]
+        L.vp9hip_decoder_last_run_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        self.handle = vp()
+        rc = L.vp9hip_decoder_create(device, ctypes.byref(self.handle))
+        if rc != 0:
+            raise Vp9HipError(f"vp9hip_decoder_create failed ({rc}): {L.vp9hip_last_error(None).decode()}")
+
+    def check(self, rc):
+        if rc != 0:
+            raise Vp9HipError(f"vp9hip_decoder call failed ({rc}): {lib().vp9hip_decoder_error(self.handle).decode()}")
+
+    @staticmethod
+    def host_frame(planes, width, height, bit_depth):
+        h = HostFrame()
+        for p, a in enumerate(planes):
+            assert a.flags["C_CONTIGUOUS"]
+            h.plane[p], h.stride[p] = a.ctypes.data, a.shape[1]
+        h.width, h.height, h.ss_x, h.ss_y, h.bit_depth, h.hbd = width, height, 1, 1, bit_depth, int(bit_depth > 8)
+        return h
+
+    def upload(self, slot, planes, width, height, bit_depth):
+        h = self.host_frame(planes, width, height, bit_depth)
+        self.check(lib().vp9hip_decoder_upload(self.handle, slot, ctypes.byref(h)))
+
+    def download(self, slot, planes, width, height, bit_depth):
+        h = self.host_frame(planes, width, height, bit_depth)
+        self.check(lib().vp9hip_decoder_download(self.handle, slot, ctypes.byref(h)))
+
+    def alloc_slot(self, slot, width, height, bit_depth, clear=True):
+        self.check(lib().vp9hip_decoder_alloc_slot(self.handle, slot, width, height, 1, bit_depth, int(bit_depth > 8),
+                                                   int(clear)))
+
+    def begin_frame(self, params, blocks, eob_planes=None, coef_planes=None):
+        blocks = np.ascontiguousarray(blocks, BLOCK_DTYPE)
+        self._keep = [blocks]
+        cl, dq = None, None
+        if eob_planes is not None:
+            cl = CoeffLayout()
+            for p in range(3):
+                a = np.ascontiguousarray(eob_planes[p], np.int32)
+                self._keep.append(a)
+                cl.eob[p], cl.eob_stride[p] = a.ctypes.data, a.shape[1]
+        if coef_planes is not None:
+            arrs = [np.ascontiguousarray(c, np.int32) for c in coef_planes]
+            self._keep += arrs
+            dq = (ctypes.c_void_p * 3)(*[a.ctypes.data if len(a) else None for a in arrs])
+        self.check(lib().vp9hip_decoder_begin_frame(self.handle, ctypes.byref(params), blocks.ctypes.data, len(blocks),
+                                                    ctypes.byref(cl) if cl is not None else None,
+                                                    ctypes.byref(dq) if dq is not None else None))
+
+    def run(self, phases, ref_slots, dst_slot, lfm=None, thresh=None):
+        rs = (ctypes.c_int * 3)(*ref_slots)
+        self.check(lib().vp9hip_decoder_run(self.handle, phases, ctypes.byref(rs), dst_slot,
+                                            lfm.ctypes.data if lfm is not None else None,
+                                            ctypes.addressof(thresh) if thresh is not None else None))
+
+    def sync(self):
+        self.check(lib().vp9hip_decoder_sync(self.handle))
+
+    def last_run_ms(self):
+        ms = ctypes.c_float()
+        self.check(lib().vp9hip_decoder_last_run_ms(self.handle, ctypes.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.handle:
+            lib().vp9hip_decoder_destroy(self.handle)
+            self.handle = None
 
 
 class Packer:
