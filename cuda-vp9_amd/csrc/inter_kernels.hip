@@ -162,6 +162,12 @@ __device__ __forceinline__ int dot8(unsigned lo, unsigned hi, unsigned flo, unsi
 constexpr int FAST_THREADS = 256;  // 4 waves per workgroup: WG dispatch rate, not work, bounds tiny WGs
 constexpr int FAST_LDS = 7680;  // max over W of (FAST_THREADS / SL) * SLOT_BYTES (W = 4: 16 slots x 480 B)
 
+// A tile's slot (16, 32 or 64 lanes) never straddles a wavefront, and a wave's LDS operations execute
+// in issue order: the stages of a tile only need the compiler pinned and lgkmcnt drained, not a
+// workgroup barrier — with s_barrier the four waves of a workgroup waited for the slowest one six
+// times per tile.
+__device__ __forceinline__ void slot_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local"); }
+
 template <int W>
 __device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, const vp9hip_inter_task *__restrict__ tasks,
                                                 int n_tasks, const RefSet &refs, const FrameDev &dstf,
@@ -233,7 +239,7 @@ __device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, cons
         }
       }
     }
-    __syncthreads();
+    slot_sync();
     if (on) {
       // rows -> T (transposed, clipped)
       const unsigned flo = taps[(filt * 16 + subx) * 2], fhi = taps[(filt * 16 + subx) * 2 + 1];
@@ -259,7 +265,7 @@ __device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, cons
         tp[3 * C::PT] = (unsigned char)o3;
       }
     }
-    __syncthreads();
+    slot_sync();
     if (on) {
       // columns -> destination
       const unsigned flo = taps[(filt * 16 + suby) * 2], fhi = taps[(filt * 16 + suby) * 2 + 1];
@@ -299,7 +305,7 @@ __device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, cons
         }
       }
     }
-    __syncthreads();
+    slot_sync();
   }
 }
 
