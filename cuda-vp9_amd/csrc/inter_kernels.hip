@@ -196,8 +196,10 @@ __device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, cons
   const int vis_w = active ? min(TW, dstf.awidth[plane] - dx) : 0;
   const int vis_h = active ? min(h, dstf.aheight[plane] - dy) : 0;
   const int rows = h + 7;
+  static_assert(TW * 4 == C::SL, "one column-pass item per lane");
+  unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;  // first prediction of a compound tile
 
-  for (int r = 0; r < 2; ++r) {  // uniform trip count: barriers inside
+  for (int r = 0; r < 2; ++r) {
     const bool on = active && r < nref && vis_w > 0 && vis_h > 0;
     int x0 = 0, y0 = 0, subx = 0, suby = 0;
     if (on) {
@@ -288,15 +290,14 @@ __device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, cons
         if (c < vis_w) {
           unsigned char *d = dst + (size_t)(4 * m) * dstride + c;
           const int y = 4 * m;
-          if (r == 1) {
-            // loads first, then stores (see txfm_kernels.hip: avoids 4 serialised round trips)
-            const unsigned e0 = (y + 0 < vis_h) ? d[0] : 0, e1 = (y + 1 < vis_h) ? d[dstride] : 0;
-            const unsigned e2 = (y + 2 < vis_h) ? d[2 * dstride] : 0, e3 = (y + 3 < vis_h) ? d[3 * dstride] : 0;
-            if (y + 0 < vis_h) d[0] = (unsigned char)((e0 + o0 + 1) >> 1);
-            if (y + 1 < vis_h) d[dstride] = (unsigned char)((e1 + o1 + 1) >> 1);
-            if (y + 2 < vis_h) d[2 * dstride] = (unsigned char)((e2 + o2 + 1) >> 1);
-            if (y + 3 < vis_h) d[3 * dstride] = (unsigned char)((e3 + o3 + 1) >> 1);
+          if (nref == 2 && r == 0) {
+            // compound: the first prediction stays in registers (same lane -> same four samples in
+            // both passes) instead of a store + reload through memory
+            k0 = o0; k1 = o1; k2 = o2; k3 = o3;
           } else {
+            if (r == 1) {  // vpx_convolve_avg_c: ROUND_POWER_OF_TWO(dst + pred, 1)
+              o0 = (k0 + o0 + 1) >> 1; o1 = (k1 + o1 + 1) >> 1; o2 = (k2 + o2 + 1) >> 1; o3 = (k3 + o3 + 1) >> 1;
+            }
             if (y + 0 < vis_h) d[0] = (unsigned char)o0;
             if (y + 1 < vis_h) d[dstride] = (unsigned char)o1;
             if (y + 2 < vis_h) d[2 * dstride] = (unsigned char)o2;
