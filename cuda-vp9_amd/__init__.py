@@ -430,10 +430,10 @@ def sort_inter_tasks(tasks, hbd):
     """Group inter tasks into the six classes vp9hip_inter_pred_batch takes."""
     unscaled = (tasks["step_x"] == 16).all(axis=1) & (tasks["step_y"] == 16).all(axis=1)
     cls = np.full(len(tasks), 5, np.int32)
-    if not hbd:
-        # fast classes cover the VP9 block shapes: width W with height <= HMAX(W), multiple of 4
-        for k, (w, hmax) in enumerate(((4, 8), (8, 16), (16, 32), (32, 64), (64, 64))):
-            cls[unscaled & (tasks["w"] == w) & (tasks["h"] <= hmax) & (tasks["h"] % 4 == 0)] = k
+    # fast classes (8-bit and 16-bit samples) cover the VP9 block shapes: width W with height <= HMAX(W),
+    # a multiple of 4
+    for k, (w, hmax) in enumerate(((4, 8), (8, 16), (16, 32), (32, 64), (64, 64))):
+        cls[unscaled & (tasks["w"] == w) & (tasks["h"] <= hmax) & (tasks["h"] % 4 == 0)] = k
     order = np.argsort(cls, kind="stable")
     return tasks[order], [int((cls == k).sum()) for k in range(6)]
 

@@ -310,6 +310,178 @@ __device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path for 16-bit samples (high bitdepth, bd 8/10/12), unscaled references: the same tiling as
+// the 8-bit path with two samples per dword.
+//  stage   (h+7) x (TW+7) window from column x0-3 -> LDS, 16-byte chunks (8 samples)
+//  rows    lane = (window row, group of 4 outputs): 6 dwords = samples 4g..4g+11; output 4g+i is
+//          sum_k f[k]*s[4g+i+k]: even i use the dwords as they are, odd i the same dwords shifted by
+//          one sample (v_alignbit), four v_dot2_i32_i16 each; clipped to the bit depth (normative:
+//          vpx_convolve.c:311-335 highbd_convolve_horiz) and written TRANSPOSED to LDS
+//  cols    lane = (column, group of 4 output rows): the same form on the transposed intermediate
+// The 128-tap of phase 0 fits int16, so full-sample positions need no special case here.
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+template <int W>
+struct Fast16Cfg {
+  static constexpr int TW = W >= 16 ? 16 : W;
+  static constexpr int HMAX = W == 4 ? 8 : (W == 8 ? 16 : (W == 16 ? 32 : 64));
+  static constexpr int TPT = (W / TW) * (HMAX / 16 ? HMAX / 16 : 1);
+  static constexpr int SL = TW == 16 ? 64 : (TW == 8 ? 32 : 16);
+  static constexpr int DC = TW / 4;                    // groups of 4 outputs per row
+  static constexpr int NCH = (TW + 7 + 7) / 8;         // 16-byte chunks per window row
+  static constexpr int PW = NCH * 16 + 8;              // window pitch in bytes (+8: the last group reads 6 dwords)
+  static constexpr int PT = 52;                        // transposed pitch in bytes: 23 rows + pad, 13 dwords (odd)
+  static constexpr int WIN_BYTES = 23 * PW;
+  static constexpr int T_BYTES = TW * PT + 8;
+  static constexpr int SLOT_BYTES = (WIN_BYTES + T_BYTES + 15) & ~15;
+};
+constexpr int FAST16_LDS = 18432;  // max over W of (FAST_THREADS / SL) * SLOT_BYTES (W = 4: 16 slots x 1136 B)
+
+__device__ __forceinline__ int dot8_16(unsigned s0, unsigned s1, unsigned s2, unsigned s3, const uint4 &f, int maxv) {
+  short2v a, b;
+  int acc = 64;
+  __builtin_memcpy(&a, &s0, 4); __builtin_memcpy(&b, &f.x, 4); acc = __builtin_amdgcn_sdot2(a, b, acc, false);
+  __builtin_memcpy(&a, &s1, 4); __builtin_memcpy(&b, &f.y, 4); acc = __builtin_amdgcn_sdot2(a, b, acc, false);
+  __builtin_memcpy(&a, &s2, 4); __builtin_memcpy(&b, &f.z, 4); acc = __builtin_amdgcn_sdot2(a, b, acc, false);
+  __builtin_memcpy(&a, &s3, 4); __builtin_memcpy(&b, &f.w, 4); acc = __builtin_amdgcn_sdot2(a, b, acc, false);
+  acc >>= 7;
+  return acc < 0 ? 0 : (acc > maxv ? maxv : acc);
+}
+
+// four consecutive outputs from six dwords (twelve samples)
+__device__ __forceinline__ void four_outputs(const unsigned *d, const uint4 &f, int maxv, int *o) {
+  const unsigned a01 = __builtin_amdgcn_alignbit(d[1], d[0], 16), a12 = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+  const unsigned a23 = __builtin_amdgcn_alignbit(d[3], d[2], 16), a34 = __builtin_amdgcn_alignbit(d[4], d[3], 16);
+  const unsigned a45 = __builtin_amdgcn_alignbit(d[5], d[4], 16);
+  o[0] = dot8_16(d[0], d[1], d[2], d[3], f, maxv);
+  o[1] = dot8_16(a01, a12, a23, a34, f, maxv);
+  o[2] = dot8_16(d[1], d[2], d[3], d[4], f, maxv);
+  o[3] = dot8_16(a12, a23, a34, a45, f, maxv);
+}
+
+template <int W>
+__device__ __forceinline__ void inter_fast16_body(unsigned char *lds, int wg, const vp9hip_inter_task *__restrict__ tasks,
+                                                  int n_tasks, const RefSet &refs, const FrameDev &dstf) {
+  typedef Fast16Cfg<W> C;
+  constexpr int TW = C::TW;
+  constexpr int GW = FAST_THREADS / C::SL;
+  static_assert(GW * C::SLOT_BYTES <= FAST16_LDS, "LDS budget");
+  static_assert(TW * 4 == C::SL, "one column-pass item per lane");
+  const int g = threadIdx.x / C::SL, sl = threadIdx.x % C::SL;
+  const int wid = wg * GW + g;
+  const int ti = wid / C::TPT, tile = wid - ti * C::TPT;
+  const int tx = tile % (W / TW), ty = tile / (W / TW);
+  bool active = ti < n_tasks;
+  vp9hip_inter_task t;
+  if (active) t = tasks[ti];
+  active = active && ty * 16 < t.h;
+  unsigned char *win = lds + g * C::SLOT_BYTES;
+  unsigned char *T = win + C::WIN_BYTES;
+  const int plane = active ? t.plane : 0;
+  const int h = active ? min(16, (int)t.h - ty * 16) : 0;
+  const int filt = active ? (t.flags >> 1) & 7 : 0;
+  const int nref = active ? ((t.flags & 1) ? 2 : 1) : 0;
+  const int maxv = (1 << dstf.bit_depth) - 1;
+  uint16_t *dplane = (uint16_t *)dstf.plane[plane];
+  const int dstride = dstf.stride[plane];
+  const int dx = active ? t.dst_x + tx * TW : 0, dy = active ? t.dst_y + ty * 16 : 0;
+  const int vis_w = active ? min(TW, dstf.awidth[plane] - dx) : 0;
+  const int vis_h = active ? min(h, dstf.aheight[plane] - dy) : 0;
+  const int rows = h + 7;
+  const uint4 *taps = (const uint4 *)&kFilters[0][0][0];  // (f0,f1) (f2,f3) (f4,f5) (f6,f7) per (filter, phase)
+  int k0 = 0, k1 = 0, k2 = 0, k3 = 0;  // first prediction of a compound tile
+
+  for (int r = 0; r < 2; ++r) {
+    const bool on = active && r < nref && vis_w > 0 && vis_h > 0;
+    int x0 = 0, y0 = 0, subx = 0, suby = 0;
+    if (on) {
+      const int px = t.pos_x[r] + tx * TW * 16, py = t.pos_y[r] + ty * 16 * 16;
+      x0 = px >> 4;
+      y0 = py >> 4;
+      subx = px & 15;
+      suby = py & 15;
+      const FrameDev &rf = refs.f[t.ref[r]];
+      const uint16_t *src = (const uint16_t *)rf.plane[plane];
+      const int sstride = rf.stride[plane];
+      const int fw = rf.width[plane], fh = rf.height[plane];
+      const bool interior = x0 - 3 >= 0 && x0 - 3 + C::NCH * 8 <= fw && y0 - 3 >= 0 && y0 + h + 4 <= fh - 1;
+      if (interior) {
+        const uint16_t *base = src + (size_t)(y0 - 3) * sstride + (x0 - 3);
+        for (int i = sl; i < rows * C::NCH; i += C::SL) {
+          const int rr = i / C::NCH, ch = i - rr * C::NCH;
+          uint4 v;
+          __builtin_memcpy(&v, base + (size_t)rr * sstride + ch * 8, 16);
+          *(uint4 *)(win + rr * C::PW + ch * 16) = v;
+        }
+      } else {
+        uint16_t *w16 = (uint16_t *)win;
+        for (int i = sl; i < rows * (TW + 7); i += C::SL) {
+          const int rr = i / (TW + 7), cc = i - rr * (TW + 7);
+          int sx = x0 - 3 + cc, sy = y0 - 3 + rr;
+          sx = sx < 0 ? 0 : (sx > fw - 1 ? fw - 1 : sx);
+          sy = sy < 0 ? 0 : (sy > fh - 1 ? fh - 1 : sy);
+          w16[rr * (C::PW / 2) + cc] = src[(size_t)sy * sstride + sx];
+        }
+      }
+    }
+    slot_sync();
+    if (on) {
+      // rows -> T (transposed, clipped)
+      const uint4 f = taps[filt * 16 + subx];
+      const unsigned *win32 = (const unsigned *)win;
+      uint16_t *T16 = (uint16_t *)T;
+      for (int i = sl; i < rows * C::DC; i += C::SL) {
+        const int rr = i / C::DC, j = i - rr * C::DC;
+        const unsigned *wp = win32 + rr * (C::PW / 4) + 2 * j;
+        unsigned d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = wp[k];
+        int o[4];
+        four_outputs(d, f, maxv, o);
+        uint16_t *tp = T16 + (4 * j) * (C::PT / 2) + rr;
+        tp[0] = (uint16_t)o[0];
+        tp[C::PT / 2] = (uint16_t)o[1];
+        tp[2 * (C::PT / 2)] = (uint16_t)o[2];
+        tp[3 * (C::PT / 2)] = (uint16_t)o[3];
+      }
+    }
+    slot_sync();
+    if (on) {
+      // columns -> destination: lane = (column c, output rows 4m..4m+3)
+      const uint4 f = taps[filt * 16 + suby];
+      const unsigned *T32 = (const unsigned *)T;
+      uint16_t *dst = dplane + (size_t)dy * dstride + dx;
+      const int i = sl;
+      const int m = i / TW, c = i - m * TW;
+      if (m < (h >> 2)) {
+        const unsigned *tp = T32 + c * (C::PT / 4) + 2 * m;
+        unsigned d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = tp[k];
+        int o[4];
+        four_outputs(d, f, maxv, o);
+        if (c < vis_w) {
+          uint16_t *dd = dst + (size_t)(4 * m) * dstride + c;
+          const int y = 4 * m;
+          if (nref == 2 && r == 0) {
+            k0 = o[0]; k1 = o[1]; k2 = o[2]; k3 = o[3];
+          } else {
+            if (r == 1) {  // vpx_highbd_convolve_avg_c: ROUND_POWER_OF_TWO(dst + pred, 1)
+              o[0] = (k0 + o[0] + 1) >> 1; o[1] = (k1 + o[1] + 1) >> 1; o[2] = (k2 + o[2] + 1) >> 1; o[3] = (k3 + o[3] + 1) >> 1;
+            }
+            if (y + 0 < vis_h) dd[0] = (uint16_t)o[0];
+            if (y + 1 < vis_h) dd[dstride] = (uint16_t)o[1];
+            if (y + 2 < vis_h) dd[2 * dstride] = (uint16_t)o[2];
+            if (y + 3 < vis_h) dd[3 * dstride] = (uint16_t)o[3];
+          }
+        }
+      }
+    }
+    slot_sync();
+  }
+}
+
 // All five width classes in one launch: workgroups [wg_start[k], wg_start[k+1]) serve class k.
 struct FastPlan {
   int wg_start[6];
@@ -359,6 +531,27 @@ __global__ __launch_bounds__(FAST_THREADS) void inter_fast_kernel(const vp9hip_i
                         plan.task_count[4], refs, dstf, taps);
 }
 
+__global__ __launch_bounds__(FAST_THREADS) void inter_fast16_kernel(const vp9hip_inter_task *__restrict__ tasks,
+                                                                    FastPlan plan, RefSet refs, FrameDev dstf) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FAST16_LDS];
+  const int b = blockIdx.x;
+  if (b < plan.wg_start[1])
+    inter_fast16_body<4>(lds, xcd_order(b, plan.wg_start[0], plan.wg_start[1]), tasks + plan.task_start[0],
+                         plan.task_count[0], refs, dstf);
+  else if (b < plan.wg_start[2])
+    inter_fast16_body<8>(lds, xcd_order(b, plan.wg_start[1], plan.wg_start[2]), tasks + plan.task_start[1],
+                         plan.task_count[1], refs, dstf);
+  else if (b < plan.wg_start[3])
+    inter_fast16_body<16>(lds, xcd_order(b, plan.wg_start[2], plan.wg_start[3]), tasks + plan.task_start[2],
+                          plan.task_count[2], refs, dstf);
+  else if (b < plan.wg_start[4])
+    inter_fast16_body<32>(lds, xcd_order(b, plan.wg_start[3], plan.wg_start[4]), tasks + plan.task_start[3],
+                          plan.task_count[3], refs, dstf);
+  else
+    inter_fast16_body<64>(lds, xcd_order(b, plan.wg_start[4], plan.wg_start[5]), tasks + plan.task_start[4],
+                          plan.task_count[4], refs, dstf);
+}
+
 template <int W>
 int fast_wgs(int n) {
   constexpr int GW = FAST_THREADS / FastCfg<W>::SL;
@@ -402,12 +595,9 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
     if (class_count[i] < 0) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_inter_pred_batch: negative class count");
     if (i < 5) fast_total += class_count[i];
   }
-  if (fast_total && dst->hbd)
-    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_inter_pred_batch: width classes 0..4 are for 8-bit frames; put "
-                                    "16-bit tasks in class 5");
   const FrameDev d = to_dev(dst);
   int rc;
-  if (fast_total && (rc = upload_taps(ctx))) return rc;
+  if (fast_total && !dst->hbd && (rc = upload_taps(ctx))) return rc;
   const vp9hip_inter_task *p = d_tasks + fast_total;
   if (fast_total) {
     FastPlan plan;
@@ -422,8 +612,11 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
       acc_t += class_count[k];
     }
     plan.wg_start[5] = acc_w;
-    hipLaunchKernelGGL(inter_fast_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d,
-                       (const unsigned *)ctx->d_taps);
+    if (dst->hbd)
+      hipLaunchKernelGGL(inter_fast16_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d);
+    else
+      hipLaunchKernelGGL(inter_fast_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d,
+                         (const unsigned *)ctx->d_taps);
     VP9HIP_CHECK(ctx, hipGetLastError());
   }
   const int n_gen = class_count[5];

@@ -470,7 +470,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
             }
             {
               int cls = 5;
-              if (!P->hbd && !any_scaled) cls = t->w == 4 ? 0 : t->w == 8 ? 1 : t->w == 16 ? 2 : t->w == 32 ? 3 : 4;
+              if (!any_scaled) cls = t->w == 4 ? 0 : t->w == 8 ? 1 : t->w == 16 ? 2 : t->w == 32 ? 3 : 4;
               key[ni] = cls;
             }
             ++ni;

@@ -141,9 +141,10 @@ typedef struct vp9hip_inter_task {
 
 #define VP9HIP_MAX_REFS 8
 /* d_tasks (DEVICE) is grouped into six classes, class_count[] (HOST) giving their sizes in order:
- *   0..4  8-bit, unscaled (step 16) tasks of width 4, 8, 16, 32, 64 and height a multiple of 4 not
- *         above 8, 16, 32, 64, 64 respectively (the VP9 block shapes)  -> LDS/dot4 fast kernels
- *   5     everything else (16-bit samples, scaled references)          -> generic kernel
+ *   0..4  unscaled (step 16) tasks of width 4, 8, 16, 32, 64 and height a multiple of 4 not above
+ *         8, 16, 32, 64, 64 respectively (the VP9 block shapes)  -> LDS fast kernels (dot4 on 8-bit
+ *         samples, dot2 on 16-bit samples)
+ *   5     everything else (scaled references, other shapes)      -> generic kernel
  * Tasks must not overlap in the destination.  Asynchronous on the context's stream. */
 int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task *d_tasks, const int32_t class_count[6],
                             const vp9hip_frame *refs, int n_refs, const vp9hip_frame *dst);
