@@ -82,6 +82,7 @@ def _oracle_frame(hip, oracle, P, blocks, coef, eob, refs, W, H, bd, th):
     (200, 136, 12, 0, 6, dict(compound_frac=0.5)),
     (1280, 720, 8, 2, 0, dict(levels=(0, 8, 30, 63))),
     (256, 256, 8, 0, 0, dict(all_intra=True)),
+    (2560, 1440, 8, 3, 0, dict(intra_frac=0.08)),   # BASELINE.json's frame size, 8 tile columns
 ])
 def test_decoder_three_phases_match_oracle(hip, oracle, W, H, bd, tiles, sharp, kw):
     import cuda_vp9_amd.workload as workload
