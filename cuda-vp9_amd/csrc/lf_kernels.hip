@@ -676,14 +676,41 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   if (wave == 1) bulk_writeback(ncols - 1);
 }
 
+// islands per superblock row the overlapped loop filter waits for (a kernel argument: no buffer whose
+// lifetime would have to outlast the launch)
+struct GateExpected {
+  int n[64];
+};
+
 template <typename Pix>
 __global__ __launch_bounds__(192) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                                        LfThreshDev th, FrameDev f, int mi_rows, int *progress,
-                                                       int *err) {
+                                                       int *err, const int *gate, GateExpected gexp) {
   __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
   __shared__ unsigned ctls[2 * 256];
   __shared__ unsigned flags[2];
   const int sr = blockIdx.x, pl = blockIdx.y;
+  if (gate != nullptr) {
+    // Running beside the intra island walk (vp9hip_intra_islands_lf): this row filters samples of
+    // superblock rows <= sr and must leave row sr+1's intra prediction its unfiltered neighbours, so
+    // it starts once every island touching rows <= sr+1 has finished (gate[r] islands done of
+    // gexp.n[r] expected).  Consumer half of the hand-off recipe: poll at agent scope (bounded), acquire,
+    // workgroup barrier, then plain loads.
+    if (threadIdx.x == 0) {
+      const int last = min(sr + 1, sb_rows - 1);
+      int spins = 0;
+      for (int r = 0; r <= last; ++r)
+        while (__hip_atomic_load(&gate[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gexp.n[r]) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > LF_SPIN_LIMIT) {
+            atomicExch(err, 1);
+            break;
+          }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
   // progress[0 .. 3*sb_rows): horizontal-pass counters; [3*sb_rows .. 6*sb_rows): vertical-pass counters
   int *hprev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
   int *hmine = progress + pl * sb_rows + sr;
@@ -711,10 +738,13 @@ __global__ __launch_bounds__(64) void lf_rows_kernel(const vp9hip_lfm *__restric
 
 }  // namespace
 
-extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
-                                        const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes) {
-  if (!ctx) return VP9HIP_EINVAL;
-  VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the caller's thread may be on another device
+static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
+                     const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes, const int *d_gate,
+                     const int32_t *h_rows_expected) {
+  GateExpected gexp;
+  memset(&gexp, 0, sizeof(gexp));
+  if (d_gate)
+    for (int r = 0; r < sb_rows && r < 64; ++r) gexp.n[r] = h_rows_expected[r];
   if (!d_lfm || sb_rows <= 0 || sb_cols <= 0 || !h_thresh || !frame_ok(frame) || (planes != 1 && planes != 3))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_loop_filter_frame: bad argument");
   if (sb_rows != (frame->aheight[0] + 63) / 64 || sb_cols != (frame->awidth[0] + 63) / 64)
@@ -726,31 +756,32 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
   memcpy(&th, h_thresh, sizeof(th));
   const FrameDev f = to_dev(frame);
   const int mi_rows = frame->aheight[0] / 8;
-  static int mode = -1;  // 0: one launch per anti-diagonal, 1: row walk (1 wave), 2: row walk (2 waves)
+  static int mode = -1;  // 0: one launch per anti-diagonal, 1: row walk (1 wave), 2: row walk (3 waves)
   if (mode < 0) {
     const char *e = getenv("VP9HIP_LF_MODE");
     mode = (e && !strcmp(e, "diag")) ? 0 : (e && !strcmp(e, "rows")) ? 1 : 2;
   }
+  if (d_gate && mode != 2) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "the overlapped loop filter needs the default row-walk mode");
   if (mode != 0) {
     // one launch: a workgroup per (superblock row, plane), progress counters in context scratch
     const size_t need = (size_t)(6 * sb_rows + 1) * sizeof(int);
     int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
     if (rc) return rc;
     int *progress = (int *)ctx->scratch, *err = progress + 6 * sb_rows;
-    VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
+    VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, st));
     ctx->lf_err_flag = err;
     if (mode == 2) {
       if (frame->hbd)
-        hipLaunchKernelGGL(lf_rows2_kernel<uint16_t>, dim3(sb_rows, planes), dim3(192), 0, ctx->stream, d_lfm, sb_cols,
-                           sb_rows, th, f, mi_rows, progress, err);
+        hipLaunchKernelGGL(lf_rows2_kernel<uint16_t>, dim3(sb_rows, planes), dim3(192), 0, st, d_lfm, sb_cols,
+                           sb_rows, th, f, mi_rows, progress, err, d_gate, gexp);
       else
-        hipLaunchKernelGGL(lf_rows2_kernel<uint8_t>, dim3(sb_rows, planes), dim3(192), 0, ctx->stream, d_lfm, sb_cols,
-                           sb_rows, th, f, mi_rows, progress, err);
+        hipLaunchKernelGGL(lf_rows2_kernel<uint8_t>, dim3(sb_rows, planes), dim3(192), 0, st, d_lfm, sb_cols,
+                           sb_rows, th, f, mi_rows, progress, err, d_gate, gexp);
     } else if (frame->hbd)
-      hipLaunchKernelGGL(lf_rows_kernel<uint16_t>, dim3(sb_rows, planes), dim3(64), 0, ctx->stream, d_lfm, sb_cols,
+      hipLaunchKernelGGL(lf_rows_kernel<uint16_t>, dim3(sb_rows, planes), dim3(64), 0, st, d_lfm, sb_cols,
                          sb_rows, th, f, mi_rows, progress, err);
     else
-      hipLaunchKernelGGL(lf_rows_kernel<uint8_t>, dim3(sb_rows, planes), dim3(64), 0, ctx->stream, d_lfm, sb_cols,
+      hipLaunchKernelGGL(lf_rows_kernel<uint8_t>, dim3(sb_rows, planes), dim3(64), 0, st, d_lfm, sb_cols,
                          sb_rows, th, f, mi_rows, progress, err);
     VP9HIP_CHECK(ctx, hipGetLastError());
     return VP9HIP_OK;
@@ -765,12 +796,59 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
     const int cnt = r_max - r_min + 1;
     if (cnt <= 0) continue;
     if (frame->hbd)
-      hipLaunchKernelGGL(lf_diag_kernel<uint16_t>, dim3(cnt, planes), dim3(64), 0, ctx->stream, d_lfm, sb_cols, t,
+      hipLaunchKernelGGL(lf_diag_kernel<uint16_t>, dim3(cnt, planes), dim3(64), 0, st, d_lfm, sb_cols, t,
                          r_min, th, f, mi_rows);
     else
-      hipLaunchKernelGGL(lf_diag_kernel<uint8_t>, dim3(cnt, planes), dim3(64), 0, ctx->stream, d_lfm, sb_cols, t,
+      hipLaunchKernelGGL(lf_diag_kernel<uint8_t>, dim3(cnt, planes), dim3(64), 0, st, d_lfm, sb_cols, t,
                          r_min, th, f, mi_rows);
   }
   VP9HIP_CHECK(ctx, hipGetLastError());
   return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
+                                        const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes) {
+  if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the caller's thread may be on another device
+  return lf_launch(ctx, ctx->stream, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, nullptr, nullptr);
+}
+
+// Intra island walk and loop filter side by side: islands on the context's stream, the loop filter
+// on a second stream; a filter row starts when the islands of its superblock rows are done (gate
+// counters), not when the whole walk is.  Both kernels are ordered after everything enqueued before
+// (event fork) and the context's stream continues after both (event join).
+extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
+                                       const vp9hip_intra_island *d_islands, int n_islands,
+                                       const int32_t *d_wave_off, const int32_t *d_coeffs,
+                                       const int32_t *h_rows_expected, const vp9hip_lfm *d_lfm, int sb_rows,
+                                       int sb_cols, const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame,
+                                       int planes) {
+  if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !h_rows_expected || !frame_ok(frame))
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: bad argument");
+  if (sb_rows > 64) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: more than 64 superblock rows");
+  if (n_islands == 0) return lf_launch(ctx, ctx->stream, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, nullptr, nullptr);
+  if (!ctx->stream2) {
+    VP9HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_gate, 64 * sizeof(int)));
+  }
+  // scratch for the filter's progress counters must exist before the fork (growing it synchronises)
+  {
+    const size_t need = (size_t)(6 * sb_rows + 1) * sizeof(int);
+    int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
+    if (rc) return rc;
+  }
+  VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->d_gate, 0, 64 * sizeof(int), ctx->stream));
+  VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  VP9HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  int rc = vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, ctx->d_gate);
+  if (rc) return rc;
+  rc = lf_launch(ctx, ctx->stream2, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, ctx->d_gate, h_rows_expected);
+  // join even if the filter launch failed, so that the context's stream stays ordered
+  (void)hipEventRecord(ctx->ev_join, ctx->stream2);
+  (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+  return rc;
 }

@@ -36,6 +36,7 @@ struct vp9hip_decoder {
   vp9hip_packed packed;
   int32_t *big_wave_start;  // host copy (the packer's array is reused by the next frame)
   size_t big_wave_cap;
+  int32_t rows_expected[64];  // islands per superblock row of the frame begun last
   bool timed;
 };
 
@@ -255,6 +256,9 @@ extern "C" int vp9hip_decoder_begin_frame(vp9hip_decoder *dec, const vp9hip_fram
     }
   }
   memcpy(dec->big_wave_start, P->big_wave_start, sizeof(int32_t) * (size_t)(P->n_big_waves + 1));
+  memset(dec->rows_expected, 0, sizeof(dec->rows_expected));
+  if (P->island_rows_expected)
+    for (int r = 0; r < P->sb_rows && r < 64; ++r) dec->rows_expected[r] = P->island_rows_expected[r];
   if ((rc = dv_reserve(dec, &dec->d_coeffs, sizeof(int32_t) * (size_t)(P->coeff_total + 16)))) return rc;
   dec->have_coeffs = dqcoeff != NULL;
   if (dqcoeff)
@@ -413,13 +417,31 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
       }
       DEC_HIP(dec, hipGetLastError());
     }
-    if (P->n_islands)
-      DEC_CTX(dec, vp9hip_intra_pred_islands(dec->ctx, (const vp9hip_intra_task *)dec->d_isl_tasks.p,
-                                             (const vp9hip_intra_island *)dec->d_islands.p, P->n_islands,
-                                             (const int32_t *)dec->d_wave_off.p, coeffs, dst));
-    if (P->n_intra_big_tasks)
-      DEC_CTX(dec, vp9hip_intra_pred_waves(dec->ctx, (const vp9hip_intra_task *)dec->d_big_tasks.p, dec->big_wave_start,
-                                           P->n_big_waves, coeffs, dst));
+    // islands and the loop filter side by side when both phases are asked for and nothing forces the
+    // sequence (key frames' large components, an explicit mask array that must be uploaded first is fine)
+    const bool overlap = (phases & VP9HIP_PHASE_LF) && thresh && P->n_islands && !P->n_intra_big_tasks && P->sb_rows <= 64 &&
+                         (h_lfm || P->lfm);
+    if (overlap) {
+      if (h_lfm) {
+        int rc = dv_upload(dec, &dec->d_lfm, h_lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols);
+        if (rc) return rc;
+        DEC_HIP(dec, hipStreamSynchronize(st));
+      }
+      DEC_CTX(dec, vp9hip_intra_islands_lf(dec->ctx, (const vp9hip_intra_task *)dec->d_isl_tasks.p,
+                                           (const vp9hip_intra_island *)dec->d_islands.p, P->n_islands,
+                                           (const int32_t *)dec->d_wave_off.p, coeffs, dec->rows_expected,
+                                           (const vp9hip_lfm *)dec->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
+                                           dec->params.ss_x ? 3 : 1));
+      phases &= ~VP9HIP_PHASE_LF;
+    } else {
+      if (P->n_islands)
+        DEC_CTX(dec, vp9hip_intra_pred_islands(dec->ctx, (const vp9hip_intra_task *)dec->d_isl_tasks.p,
+                                               (const vp9hip_intra_island *)dec->d_islands.p, P->n_islands,
+                                               (const int32_t *)dec->d_wave_off.p, coeffs, dst));
+      if (P->n_intra_big_tasks)
+        DEC_CTX(dec, vp9hip_intra_pred_waves(dec->ctx, (const vp9hip_intra_task *)dec->d_big_tasks.p, dec->big_wave_start,
+                                             P->n_big_waves, coeffs, dst));
+    }
   }
 
   if (phases & VP9HIP_PHASE_LF) {

@@ -28,7 +28,7 @@ struct vp9hip_packer {
   vec inter, inter_sorted, txb, txb_sorted, intra, intra_isl, intra_big, islands, wave_off, big_wave_start;
   vec level, parent, comp_id, comp_size, order_a, order_b, count;
   vec lvl_map[3], own_map[3];
-  vec lfm, lf_raw;
+  vec lfm, lf_raw, rows_expected;
 };
 
 static int vec_reserve(vec *v, size_t bytes) {
@@ -54,7 +54,7 @@ void vp9hip_packer_destroy(vp9hip_packer *pk) {
                  &pk->intra_big, &pk->islands,     &pk->wave_off,  &pk->big_wave_start, &pk->level, &pk->parent,
                  &pk->comp_id,  &pk->comp_size,    &pk->order_a,   &pk->order_b,    &pk->count,    &pk->lvl_map[0],
                  &pk->lvl_map[1], &pk->lvl_map[2], &pk->own_map[0], &pk->own_map[1], &pk->own_map[2], &pk->lfm,
-                 &pk->lf_raw };
+                 &pk->lf_raw,   &pk->rows_expected };
   for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) free(all[i]->p);
   free(pk);
 }
@@ -636,6 +636,10 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
     int32_t *k1 = (int32_t *)pk->order_a.p, *k2 = k1 + na + 1;
     vp9hip_intra_task *tmp = (vp9hip_intra_task *)pk->inter.p; /* scratch: the unsorted inter list is dead */
     int n_isl = 0, n_big = 0;
+    if (vec_reserve(&pk->rows_expected, sizeof(int32_t) * (size_t)(sb_rows + 1))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+    int32_t *rexp = (int32_t *)pk->rows_expected.p;
+    memset(rexp, 0, sizeof(int32_t) * (size_t)(sb_rows + 1));
+    out->island_rows_expected = rexp;
     /* gather, keeping decode order */
     for (int i = 0; i < na; ++i) {
       if (csize[comp[i]] > MAX_ISLAND_TASKS) {
@@ -711,6 +715,20 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
           ++e;
         }
         wo[n_wo++] = e - a;
+        /* luma superblock rows the island's samples lie in (all its tasks are in one plane) */
+        {
+          int ylo = INT_MAX, yhi = 0;
+          for (int k = a; k < e; ++k) {
+            const vp9hip_intra_task *t = &isl[k];
+            const int sc = t->plane ? ss : 0, y0 = t->y << sc, y1 = (t->y + (4 << t->tx_size)) << sc;
+            if (y0 < ylo) ylo = y0;
+            if (y1 > yhi) yhi = y1;
+          }
+          int lo = ylo >> 6, hi = (yhi - 1) >> 6;
+          if (hi > sb_rows - 1) hi = sb_rows - 1;
+          r->reserved = (uint32_t)lo | ((uint32_t)hi << 16);
+          for (int q = lo; q <= hi; ++q) ++rexp[q];
+        }
         a = e;
       }
       out->islands = is;

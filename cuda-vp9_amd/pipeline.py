@@ -30,6 +30,7 @@ class FrameJob:
         self.d_isl_woff = ctx.alloc(wl["intra_island_wave_off"])
         self.d_big_tasks = ctx.alloc(wl["intra_big_tasks"]) if len(wl["intra_big_tasks"]) else None
         self.use_islands = True
+        self.overlap = True
         self.d_lfm = ctx.alloc(wl["lfm"])
         self.th = LfThresh()
         mblim, lim, hev = wl["thresholds"]
@@ -46,6 +47,15 @@ class FrameJob:
             ctx.inter_pred_batch(self.d_inter, self.inter_counts, self.refs, self.dst)
         if "txb" in phases and self.d_txb is not None:
             ctx.idct_add_batch(self.d_txb, wl["txb_counts"], self.d_coeffs, self.dst)
+        # intra + loop filter of the same frame overlap (islands on one HIP stream, the filter on
+        # another, rows gated on the islands they depend on) unless the frame has components too
+        # large for an island (key frames) or only one of the two phases is asked for
+        if ("intra" in phases and "lf" in phases and self.use_islands and self.overlap and self.d_islands is not None
+                and self.d_big_tasks is None and wl["sb_rows"] <= 64):
+            ctx.intra_islands_lf(self.d_isl_tasks, self.d_islands, len(wl["intra_islands"]), self.d_isl_woff,
+                                 self.d_coeffs, wl["island_rows_expected"], self.d_lfm, wl["sb_rows"], wl["sb_cols"],
+                                 self.th, self.dst, 3)
+            return
         if "intra" in phases and self.d_intra is not None:
             if self.use_islands:
                 # islands: one launch; components too large for one workgroup keep per-wave launches

@@ -253,6 +253,15 @@ def intra_levels(tasks, dims, want_components=False):
     return lv
 
 
+def island_rows_expected(islands, sb_rows):
+    """expected[r] = number of islands whose samples touch luma superblock row r."""
+    exp = np.zeros(sb_rows, np.int32)
+    for r in islands:
+        lo, hi = int(r["reserved"]) & 0xffff, min(int(r["reserved"]) >> 16, sb_rows - 1)
+        exp[lo:hi + 1] += 1
+    return exp
+
+
 def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
     """Split the intra tasks into islands (one workgroup each, vp9hip_intra_pred_islands) and a
     remainder of very large components that keeps the per-wave launches."""
@@ -274,7 +283,11 @@ def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
         for a, b in zip(starts, ends):
             lv = l_sorted[a:b]
             w = np.flatnonzero(np.r_[True, lv[1:] != lv[:-1]])
-            islands.append((a, len(wave_off), len(w), 0))
+            t = isl_tasks[a:b]
+            sc = np.where(t["plane"] > 0, 1, 0)
+            lo = int((t["y"].astype(np.int64) << sc).min()) >> 6
+            hi = (int(((t["y"].astype(np.int64) + (4 << t["tx_size"].astype(np.int64))) << sc).max()) - 1) >> 6
+            islands.append((a, len(wave_off), len(w), lo | (hi << 16)))
             wave_off.extend(w.tolist())
             wave_off.append(b - a)
     islands = np.array(islands, dtype=ISLAND_DTYPE) if islands else np.zeros(0, ISLAND_DTYPE)
@@ -452,5 +465,6 @@ def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_fr
                 intra_decode_order=itasks, intra_sorted=itasks_sorted, wave_start=wave_start, n_waves=n_waves,
                 intra_island_tasks=isl_tasks, intra_islands=islands, intra_island_wave_off=isl_wave_off,
                 intra_big_tasks=big_tasks, intra_big_wave_start=big_wave_start,
+                island_rows_expected=island_rows_expected(islands, sb_rows),
                 lfm=lfm, sb_rows=sb_rows, sb_cols=sb_cols, thresholds=lf_thresholds(sharpness),
                 n_blocks=nb, n_txb=nt)

@@ -40,6 +40,13 @@ def test_frame_pipeline_matches_oracle(hip, oracle, W, H, bd, kw):
     ctx.sync()
     again = job.download()
     assert all(np.array_equal(a, b) for a, b in zip(got, again))
+    # the sequential form (islands, then the loop filter) and the overlapped one agree
+    job.overlap = False
+    job.clear_dst()
+    job.run()
+    ctx.sync()
+    seq = job.download()
+    assert all(np.array_equal(a, b) for a, b in zip(got, seq))
     job.free()
     ctx.close()
 
