@@ -77,7 +77,7 @@ class Packed(ctypes.Structure):
                 ("intra_island_tasks", ctypes.c_void_p), ("n_intra_island_tasks", ctypes.c_int32),
                 ("islands", ctypes.c_void_p), ("n_islands", ctypes.c_int32),
                 ("island_wave_off", ctypes.c_void_p), ("n_island_wave_off", ctypes.c_int32),
-                ("island_rows_expected", ctypes.c_void_p),
+                ("island_sb_expected", ctypes.c_void_p),
                 ("intra_big_tasks", ctypes.c_void_p), ("n_intra_big_tasks", ctypes.c_int32),
                 ("big_wave_start", ctypes.c_void_p), ("n_big_waves", ctypes.c_int32),
                 ("intra_decode_order", ctypes.c_void_p), ("n_intra", ctypes.c_int32),
@@ -268,7 +268,7 @@ class Packer:
             intra_island_tasks=_arr(out.intra_island_tasks, out.n_intra_island_tasks, INTRA_DTYPE),
             intra_islands=_arr(out.islands, out.n_islands, ISLAND_DTYPE),
             intra_island_wave_off=_arr(out.island_wave_off, out.n_island_wave_off, np.int32),
-            island_rows_expected=_arr(out.island_rows_expected, out.sb_rows, np.int32),
+            island_sb_expected=_arr(out.island_sb_expected, out.sb_rows * out.sb_cols, np.int32),
             intra_big_tasks=_arr(out.intra_big_tasks, out.n_intra_big_tasks, INTRA_DTYPE),
             intra_big_wave_start=_arr(out.big_wave_start, out.n_big_waves + 1, np.int32),
             intra_decode_order=_arr(out.intra_decode_order, out.n_intra, INTRA_DTYPE),
@@ -417,14 +417,13 @@ class Context:
             ctypes.c_void_p(d_wave_off.ptr), ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
             ctypes.byref(frame.desc)))
 
-    def intra_islands_lf(self, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, rows_expected, d_lfm, sb_rows,
+    def intra_islands_lf(self, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, d_sb_expected, d_lfm, sb_rows,
                          sb_cols, thresh, frame, planes=3):
         """Island walk and loop filter side by side (vp9hip_intra_islands_lf)."""
-        exp = np.ascontiguousarray(rows_expected, np.int32)
         self.check(lib().vp9hip_intra_islands_lf(
             self.handle, ctypes.c_void_p(d_tasks.ptr), ctypes.c_void_p(d_islands.ptr), int(n_islands),
             ctypes.c_void_p(d_wave_off.ptr), ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
-            exp.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_lfm.ptr), int(sb_rows), int(sb_cols),
+            ctypes.c_void_p(d_sb_expected.ptr), ctypes.c_void_p(d_lfm.ptr), int(sb_rows), int(sb_cols),
             ctypes.byref(thresh), ctypes.byref(frame.desc), int(planes)))
 
     def loop_filter_frame(self, d_lfm, sb_rows, sb_cols, thresh, frame, planes=3):

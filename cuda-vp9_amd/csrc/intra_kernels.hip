@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_ta
                                                            const vp9hip_intra_island *__restrict__ islands,
                                                            const int32_t *__restrict__ wave_off,
                                                            const int32_t *__restrict__ coeffs, FrameDev f,
-                                                           int *__restrict__ rows_done) {
+                                                           int *__restrict__ sb_done, int sb_cols) {
   __shared__ int edge[SLOTS][ESIZE];
   __shared__ int tiles[SLOTS][32 * TPITCH];
   const vp9hip_intra_island isl = islands[blockIdx.x];
@@ -337,14 +337,17 @@ __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_ta
     }
     __syncthreads();
   }
-  // Overlap with the loop filter (vp9hip_intra_islands_lf): tell the rows this island touches that
+  // Overlap with the loop filter (vp9hip_intra_islands_lf): tell the superblocks this island touches that
   // it is done.  Every wave's stores are complete (the __syncthreads above drains vmcnt and joins the
   // waves); one agent-scope release writes this XCD's dirty L2 lines back, then the counters go up —
   // the producer half of the hand-off recipe of MI355X_MICROARCH.md.
-  if (rows_done != nullptr && threadIdx.x == 0) {
+  if (sb_done != nullptr && threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const int lo = (int)(isl.reserved & 0xffff), hi = (int)(isl.reserved >> 16);
-    for (int r = lo; r <= hi; ++r) __hip_atomic_fetch_add(&rows_done[r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int rlo = (int)(isl.reserved & 0xff), rhi = (int)((isl.reserved >> 8) & 0xff);
+    const int clo = (int)((isl.reserved >> 16) & 0xff), chi = (int)(isl.reserved >> 24);
+    for (int r = rlo; r <= rhi; ++r)
+      for (int c = clo; c <= chi; ++c)
+        __hip_atomic_fetch_add(&sb_done[r * sb_cols + c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -352,14 +355,14 @@ __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_ta
 
 int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
-                          const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_rows_done) {
+                          const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_sb_done, int sb_cols) {
   const FrameDev f = to_dev(frame);
   if (frame->hbd)
     hipLaunchKernelGGL((intra_island_kernel<uint16_t, true>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, f, d_rows_done);
+                       d_wave_off, d_coeffs, f, d_sb_done, sb_cols);
   else
     hipLaunchKernelGGL((intra_island_kernel<uint8_t, false>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, f, d_rows_done);
+                       d_wave_off, d_coeffs, f, d_sb_done, sb_cols);
   VP9HIP_CHECK(ctx, hipGetLastError());
   return VP9HIP_OK;
 }
@@ -373,7 +376,7 @@ extern "C" int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_tas
   if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !frame_ok(frame))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_islands: bad argument");
   if (n_islands == 0) return VP9HIP_OK;
-  return vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, nullptr);
+  return vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, nullptr, 0);
 }
 
 extern "C" int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks, const int32_t *wave_start,

@@ -504,7 +504,8 @@ template <typename Pix, int N>
 __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const vp9hip_lfm *__restrict__ lfms,
                                              int sb_cols, int sr, int pl, const LfThreshDev &th, const FrameDev &f,
                                              int mi_rows, int *vprog_prev, int *hprog_prev, int *vprog_mine,
-                                             int *hprog_mine, int *err, volatile unsigned *flags) {
+                                             int *hprog_mine, int *err, volatile unsigned *flags,
+                                             const int *gate_done, const int *gate_expected, int sb_rows) {
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int PPD = 4 / sizeof(Pix);
   constexpr int n = N;
@@ -557,6 +558,28 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         dead = true;
       }
     }
+  };
+  // Running beside the intra island walk (vp9hip_intra_islands_lf): superblock (sr, c) may be loaded
+  // and filtered once every island touching superblocks (sr..sr+1, c-1..c+1) is done — an unfinished
+  // island there still reads samples this superblock's passes change (its left / above / above-left /
+  // above-right neighbours), or has not written the samples yet.  Columns are checked as the walk
+  // reaches them.  Consumer half of the hand-off recipe: poll at agent scope (bounded), then an
+  // agent-scope acquire before the plain loads (another workgroup of this XCD may have pulled a line
+  // into L2 while an island elsewhere was still writing into it).
+  auto gate_col = [&](int col) {  // wave 1
+    if (gate_done == nullptr || col >= sb_cols) return;
+    for (int r = sr; r <= sr + 1 && r < sb_rows; ++r) {
+      const int need = gate_expected[r * sb_cols + col];
+      int spins = 0;
+      while (!dead && __hip_atomic_load(&gate_done[r * sb_cols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > LF_SPIN_LIMIT) {
+          if (lane == 0) atomicExch(err, 1);
+          dead = true;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   };
   auto fetch_above = [&](int sc) {  // wave 1: bottom 8 rows of the row above -> tile rows 0..7
     unsigned *t32 = (unsigned *)(tiles + (sc & 1) * TILE);
@@ -622,8 +645,13 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
 
+  // the filtering wave is the critical path of the frame: when it shares a SIMD with waves of the
+  // island walk running beside it, it issues first
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);
   // prologue: interior of superblock 0 into buffer 0
   if (wave == 1) {
+    gate_col(0);
+    gate_col(1);
     load_interior(0);
     store_interior(0);
   }
@@ -663,6 +691,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       }
     } else if (wave == 1) {
       if (!last) {
+        gate_col(sc + 2);  // columns sc, sc+1 were checked on the way here
         load_interior(sc + 1);
         store_interior(sc + 1);
       }
@@ -676,49 +705,24 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   if (wave == 1) bulk_writeback(ncols - 1);
 }
 
-// islands per superblock row the overlapped loop filter waits for (a kernel argument: no buffer whose
-// lifetime would have to outlast the launch)
-struct GateExpected {
-  int n[64];
-};
-
 template <typename Pix>
 __global__ __launch_bounds__(192) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                                        LfThreshDev th, FrameDev f, int mi_rows, int *progress,
-                                                       int *err, const int *gate, GateExpected gexp) {
+                                                       int *err, const int *gate_done, const int *gate_expected) {
   __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
   __shared__ unsigned ctls[2 * 256];
   __shared__ unsigned flags[2];
   const int sr = blockIdx.x, pl = blockIdx.y;
-  if (gate != nullptr) {
-    // Running beside the intra island walk (vp9hip_intra_islands_lf): this row filters samples of
-    // superblock rows <= sr and must leave row sr+1's intra prediction its unfiltered neighbours, so
-    // it starts once every island touching rows <= sr+1 has finished (gate[r] islands done of
-    // gexp.n[r] expected).  Consumer half of the hand-off recipe: poll at agent scope (bounded), acquire,
-    // workgroup barrier, then plain loads.
-    if (threadIdx.x == 0) {
-      const int last = min(sr + 1, sb_rows - 1);
-      int spins = 0;
-      for (int r = 0; r <= last; ++r)
-        while (__hip_atomic_load(&gate[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gexp.n[r]) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > LF_SPIN_LIMIT) {
-            atomicExch(err, 1);
-            break;
-          }
-        }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-  }
   // progress[0 .. 3*sb_rows): horizontal-pass counters; [3*sb_rows .. 6*sb_rows): vertical-pass counters
   int *hprev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
   int *hmine = progress + pl * sb_rows + sr;
   int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
   if (pl == 0)
-    lf_row2_body<Pix, 64>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags);
+    lf_row2_body<Pix, 64>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
+                          gate_done, gate_expected, sb_rows);
   else
-    lf_row2_body<Pix, 32>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags);
+    lf_row2_body<Pix, 32>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
+                          gate_done, gate_expected, sb_rows);
 }
 
 template <typename Pix>
@@ -740,11 +744,7 @@ __global__ __launch_bounds__(64) void lf_rows_kernel(const vp9hip_lfm *__restric
 
 static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
                      const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes, const int *d_gate,
-                     const int32_t *h_rows_expected) {
-  GateExpected gexp;
-  memset(&gexp, 0, sizeof(gexp));
-  if (d_gate)
-    for (int r = 0; r < sb_rows && r < 64; ++r) gexp.n[r] = h_rows_expected[r];
+                     const int32_t *d_sb_expected) {
   if (!d_lfm || sb_rows <= 0 || sb_cols <= 0 || !h_thresh || !frame_ok(frame) || (planes != 1 && planes != 3))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_loop_filter_frame: bad argument");
   if (sb_rows != (frame->aheight[0] + 63) / 64 || sb_cols != (frame->awidth[0] + 63) / 64)
@@ -773,10 +773,10 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
     if (mode == 2) {
       if (frame->hbd)
         hipLaunchKernelGGL(lf_rows2_kernel<uint16_t>, dim3(sb_rows, planes), dim3(192), 0, st, d_lfm, sb_cols,
-                           sb_rows, th, f, mi_rows, progress, err, d_gate, gexp);
+                           sb_rows, th, f, mi_rows, progress, err, d_gate, d_sb_expected);
       else
         hipLaunchKernelGGL(lf_rows2_kernel<uint8_t>, dim3(sb_rows, planes), dim3(192), 0, st, d_lfm, sb_cols,
-                           sb_rows, th, f, mi_rows, progress, err, d_gate, gexp);
+                           sb_rows, th, f, mi_rows, progress, err, d_gate, d_sb_expected);
     } else if (frame->hbd)
       hipLaunchKernelGGL(lf_rows_kernel<uint16_t>, dim3(sb_rows, planes), dim3(64), 0, st, d_lfm, sb_cols,
                          sb_rows, th, f, mi_rows, progress, err);
@@ -813,27 +813,30 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
   return lf_launch(ctx, ctx->stream, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, nullptr, nullptr);
 }
 
+constexpr int VP9HIP_GATE_INTS = 16384;  // island counters: up to 128 x 128 superblocks (8192 x 8192 samples)
+
 // Intra island walk and loop filter side by side: islands on the context's stream, the loop filter
-// on a second stream; a filter row starts when the islands of its superblock rows are done (gate
+// on a second stream; the filter takes a superblock when the islands around it are done (gate
 // counters), not when the whole walk is.  Both kernels are ordered after everything enqueued before
 // (event fork) and the context's stream continues after both (event join).
 extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
                                        const vp9hip_intra_island *d_islands, int n_islands,
                                        const int32_t *d_wave_off, const int32_t *d_coeffs,
-                                       const int32_t *h_rows_expected, const vp9hip_lfm *d_lfm, int sb_rows,
+                                       const int32_t *d_sb_expected, const vp9hip_lfm *d_lfm, int sb_rows,
                                        int sb_cols, const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame,
                                        int planes) {
   if (!ctx) return VP9HIP_EINVAL;
   VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !h_rows_expected || !frame_ok(frame))
+  if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !d_sb_expected || !frame_ok(frame))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: bad argument");
-  if (sb_rows > 64) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: more than 64 superblock rows");
+  if (sb_rows > 255 || sb_cols > 255 || sb_rows * sb_cols > VP9HIP_GATE_INTS)
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: frame too large (%d x %d superblocks)", sb_cols, sb_rows);
   if (n_islands == 0) return lf_launch(ctx, ctx->stream, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, nullptr, nullptr);
   if (!ctx->stream2) {
     VP9HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_gate, 64 * sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_gate, VP9HIP_GATE_INTS * sizeof(int)));
   }
   // scratch for the filter's progress counters must exist before the fork (growing it synchronises)
   {
@@ -841,12 +844,13 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
     int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
     if (rc) return rc;
   }
-  VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->d_gate, 0, 64 * sizeof(int), ctx->stream));
+  VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->d_gate, 0, (size_t)sb_rows * sb_cols * sizeof(int), ctx->stream));
   VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   VP9HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  int rc = vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, ctx->d_gate);
+  int rc = vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, ctx->d_gate,
+                                 sb_cols);
   if (rc) return rc;
-  rc = lf_launch(ctx, ctx->stream2, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, ctx->d_gate, h_rows_expected);
+  rc = lf_launch(ctx, ctx->stream2, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, ctx->d_gate, d_sb_expected);
   // join even if the filter launch failed, so that the context's stream stays ordered
   (void)hipEventRecord(ctx->ev_join, ctx->stream2);
   (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);

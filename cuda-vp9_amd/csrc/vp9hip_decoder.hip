@@ -27,7 +27,7 @@ struct vp9hip_decoder {
   vp9hip_packer *pk;
   char err[512];
   Slot slots[VP9HIP_POOL_SLOTS];
-  DevVec d_inter, d_txb, d_isl_tasks, d_islands, d_wave_off, d_big_tasks, d_lfm, d_coeffs, d_res[3];
+  DevVec d_inter, d_txb, d_isl_tasks, d_islands, d_wave_off, d_big_tasks, d_lfm, d_coeffs, d_res[3], d_sb_expected;
   int32_t res_stride[3];
   bool have_res;
   bool begun;
@@ -36,7 +36,7 @@ struct vp9hip_decoder {
   vp9hip_packed packed;
   int32_t *big_wave_start;  // host copy (the packer's array is reused by the next frame)
   size_t big_wave_cap;
-  int32_t rows_expected[64];  // islands per superblock row of the frame begun last
+
   bool timed;
 };
 
@@ -109,7 +109,7 @@ extern "C" void vp9hip_decoder_destroy(vp9hip_decoder *dec) {
     for (int p = 0; p < 3; ++p)
       if (dec->slots[s].f.plane[p]) (void)hipFree(dec->slots[s].f.plane[p]);
   DevVec *all[] = { &dec->d_inter, &dec->d_txb, &dec->d_isl_tasks, &dec->d_islands, &dec->d_wave_off, &dec->d_big_tasks,
-                    &dec->d_lfm,   &dec->d_coeffs, &dec->d_res[0], &dec->d_res[1], &dec->d_res[2] };
+                    &dec->d_lfm,   &dec->d_coeffs, &dec->d_res[0], &dec->d_res[1], &dec->d_res[2], &dec->d_sb_expected };
   for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i)
     if (all[i]->p) (void)hipFree(all[i]->p);
   free(dec->big_wave_start);
@@ -256,9 +256,9 @@ extern "C" int vp9hip_decoder_begin_frame(vp9hip_decoder *dec, const vp9hip_fram
     }
   }
   memcpy(dec->big_wave_start, P->big_wave_start, sizeof(int32_t) * (size_t)(P->n_big_waves + 1));
-  memset(dec->rows_expected, 0, sizeof(dec->rows_expected));
-  if (P->island_rows_expected)
-    for (int r = 0; r < P->sb_rows && r < 64; ++r) dec->rows_expected[r] = P->island_rows_expected[r];
+  if (P->island_sb_expected &&
+      (rc = dv_upload(dec, &dec->d_sb_expected, P->island_sb_expected, sizeof(int32_t) * (size_t)P->sb_rows * P->sb_cols)))
+    return rc;
   if ((rc = dv_reserve(dec, &dec->d_coeffs, sizeof(int32_t) * (size_t)(P->coeff_total + 16)))) return rc;
   dec->have_coeffs = dqcoeff != NULL;
   if (dqcoeff)
@@ -419,7 +419,8 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
     }
     // islands and the loop filter side by side when both phases are asked for and nothing forces the
     // sequence (key frames' large components, an explicit mask array that must be uploaded first is fine)
-    const bool overlap = (phases & VP9HIP_PHASE_LF) && thresh && P->n_islands && !P->n_intra_big_tasks && P->sb_rows <= 64 &&
+    const bool overlap = (phases & VP9HIP_PHASE_LF) && thresh && P->n_islands && !P->n_intra_big_tasks && P->sb_rows <= 128 && P->sb_cols <= 128 &&
+                         P->island_sb_expected &&
                          (h_lfm || P->lfm);
     if (overlap) {
       if (h_lfm) {
@@ -429,7 +430,7 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
       }
       DEC_CTX(dec, vp9hip_intra_islands_lf(dec->ctx, (const vp9hip_intra_task *)dec->d_isl_tasks.p,
                                            (const vp9hip_intra_island *)dec->d_islands.p, P->n_islands,
-                                           (const int32_t *)dec->d_wave_off.p, coeffs, dec->rows_expected,
+                                           (const int32_t *)dec->d_wave_off.p, coeffs, (const int32_t *)dec->d_sb_expected.p,
                                            (const vp9hip_lfm *)dec->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
                                            dec->params.ss_x ? 3 : 1));
       phases &= ~VP9HIP_PHASE_LF;

@@ -307,6 +307,14 @@ static void counting_sort(const void *src, void *dst, size_t rec, const int32_t 
     memcpy((char *)dst + (size_t)count[key[i]]++ * rec, (const char *)src + (size_t)i * rec, rec);
 }
 
+/* deepest islands first: an island is one workgroup walking its waves one after the other, so the
+ * deepest one is the critical path of the launch — and of the loop-filter rows waiting for it */
+static int island_deeper_first(const void *a, const void *b) {
+  const vp9hip_intra_island *x = (const vp9hip_intra_island *)a, *y = (const vp9hip_intra_island *)b;
+  if (x->n_waves != y->n_waves) return x->n_waves > y->n_waves ? -1 : 1;
+  return x->task_start < y->task_start ? -1 : (x->task_start > y->task_start);
+}
+
 static int uf_find(int32_t *parent, int a) {
   while (parent[a] != a) {
     parent[a] = parent[parent[a]];
@@ -636,10 +644,10 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
     int32_t *k1 = (int32_t *)pk->order_a.p, *k2 = k1 + na + 1;
     vp9hip_intra_task *tmp = (vp9hip_intra_task *)pk->inter.p; /* scratch: the unsorted inter list is dead */
     int n_isl = 0, n_big = 0;
-    if (vec_reserve(&pk->rows_expected, sizeof(int32_t) * (size_t)(sb_rows + 1))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+    if (vec_reserve(&pk->rows_expected, sizeof(int32_t) * ((size_t)sb_rows * sb_cols + 1))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
     int32_t *rexp = (int32_t *)pk->rows_expected.p;
-    memset(rexp, 0, sizeof(int32_t) * (size_t)(sb_rows + 1));
-    out->island_rows_expected = rexp;
+    memset(rexp, 0, sizeof(int32_t) * ((size_t)sb_rows * sb_cols + 1));
+    out->island_sb_expected = rexp;
     /* gather, keeping decode order */
     for (int i = 0; i < na; ++i) {
       if (csize[comp[i]] > MAX_ISLAND_TASKS) {
@@ -715,22 +723,28 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
           ++e;
         }
         wo[n_wo++] = e - a;
-        /* luma superblock rows the island's samples lie in (all its tasks are in one plane) */
+        /* luma superblocks the island's samples lie in (all its tasks are in one plane) */
         {
-          int ylo = INT_MAX, yhi = 0;
+          int ylo = INT_MAX, yhi = 0, xlo = INT_MAX, xhi = 0;
           for (int k = a; k < e; ++k) {
             const vp9hip_intra_task *t = &isl[k];
-            const int sc = t->plane ? ss : 0, y0 = t->y << sc, y1 = (t->y + (4 << t->tx_size)) << sc;
+            const int sc = t->plane ? ss : 0, bsz = 4 << t->tx_size;
+            const int y0 = t->y << sc, y1 = (t->y + bsz) << sc, x0 = t->x << sc, x1 = (t->x + bsz) << sc;
             if (y0 < ylo) ylo = y0;
             if (y1 > yhi) yhi = y1;
+            if (x0 < xlo) xlo = x0;
+            if (x1 > xhi) xhi = x1;
           }
-          int lo = ylo >> 6, hi = (yhi - 1) >> 6;
-          if (hi > sb_rows - 1) hi = sb_rows - 1;
-          r->reserved = (uint32_t)lo | ((uint32_t)hi << 16);
-          for (int q = lo; q <= hi; ++q) ++rexp[q];
+          int rlo = ylo >> 6, rhi = (yhi - 1) >> 6, clo = xlo >> 6, chi = (xhi - 1) >> 6;
+          if (rhi > sb_rows - 1) rhi = sb_rows - 1;
+          if (chi > sb_cols - 1) chi = sb_cols - 1;
+          r->reserved = (uint32_t)rlo | ((uint32_t)rhi << 8) | ((uint32_t)clo << 16) | ((uint32_t)chi << 24);
+          for (int q = rlo; q <= rhi; ++q)
+            for (int c = clo; c <= chi; ++c) ++rexp[q * sb_cols + c];
         }
         a = e;
       }
+      qsort(is, (size_t)n_is, sizeof(*is), island_deeper_first);
       out->islands = is;
       out->n_islands = n_is;
       out->island_wave_off = wo;

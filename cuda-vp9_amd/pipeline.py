@@ -29,6 +29,7 @@ class FrameJob:
         self.d_islands = ctx.alloc(wl["intra_islands"]) if len(wl["intra_islands"]) else None
         self.d_isl_woff = ctx.alloc(wl["intra_island_wave_off"])
         self.d_big_tasks = ctx.alloc(wl["intra_big_tasks"]) if len(wl["intra_big_tasks"]) else None
+        self.d_sb_expected = ctx.alloc(wl["island_sb_expected"])
         self.use_islands = True
         self.overlap = True
         self.d_lfm = ctx.alloc(wl["lfm"])
@@ -51,9 +52,9 @@ class FrameJob:
         # another, rows gated on the islands they depend on) unless the frame has components too
         # large for an island (key frames) or only one of the two phases is asked for
         if ("intra" in phases and "lf" in phases and self.use_islands and self.overlap and self.d_islands is not None
-                and self.d_big_tasks is None and wl["sb_rows"] <= 64):
+                and self.d_big_tasks is None and wl["sb_rows"] <= 255 and wl["sb_cols"] <= 255):
             ctx.intra_islands_lf(self.d_isl_tasks, self.d_islands, len(wl["intra_islands"]), self.d_isl_woff,
-                                 self.d_coeffs, wl["island_rows_expected"], self.d_lfm, wl["sb_rows"], wl["sb_cols"],
+                                 self.d_coeffs, self.d_sb_expected, self.d_lfm, wl["sb_rows"], wl["sb_cols"],
                                  self.th, self.dst, 3)
             return
         if "intra" in phases and self.d_intra is not None:
@@ -76,7 +77,7 @@ class FrameJob:
         for fr in self.refs + [self.dst]:
             fr.free()
         for b in (self.d_inter, self.d_txb, self.d_coeffs, self.d_intra, self.d_lfm, self.d_isl_tasks, self.d_islands,
-                  self.d_isl_woff, self.d_big_tasks):
+                  self.d_isl_woff, self.d_big_tasks, self.d_sb_expected):
             if b is not None:
                 b.free()
 

@@ -253,13 +253,14 @@ def intra_levels(tasks, dims, want_components=False):
     return lv
 
 
-def island_rows_expected(islands, sb_rows):
-    """expected[r] = number of islands whose samples touch luma superblock row r."""
-    exp = np.zeros(sb_rows, np.int32)
+def island_sb_expected(islands, sb_rows, sb_cols):
+    """expected[r, c] = number of islands whose samples touch luma superblock (r, c)."""
+    exp = np.zeros((sb_rows, sb_cols), np.int32)
     for r in islands:
-        lo, hi = int(r["reserved"]) & 0xffff, min(int(r["reserved"]) >> 16, sb_rows - 1)
-        exp[lo:hi + 1] += 1
-    return exp
+        v = int(r["reserved"])
+        rlo, rhi, clo, chi = v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff, (v >> 24) & 0xff
+        exp[rlo:min(rhi, sb_rows - 1) + 1, clo:min(chi, sb_cols - 1) + 1] += 1
+    return exp.ravel()
 
 
 def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
@@ -285,12 +286,18 @@ def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
             w = np.flatnonzero(np.r_[True, lv[1:] != lv[:-1]])
             t = isl_tasks[a:b]
             sc = np.where(t["plane"] > 0, 1, 0)
-            lo = int((t["y"].astype(np.int64) << sc).min()) >> 6
-            hi = (int(((t["y"].astype(np.int64) + (4 << t["tx_size"].astype(np.int64))) << sc).max()) - 1) >> 6
-            islands.append((a, len(wave_off), len(w), lo | (hi << 16)))
+            bsz = 4 << t["tx_size"].astype(np.int64)
+            rlo = int((t["y"].astype(np.int64) << sc).min()) >> 6
+            rhi = (int(((t["y"].astype(np.int64) + bsz) << sc).max()) - 1) >> 6
+            clo = int((t["x"].astype(np.int64) << sc).min()) >> 6
+            chi = (int(((t["x"].astype(np.int64) + bsz) << sc).max()) - 1) >> 6
+            islands.append((a, len(wave_off), len(w), rlo | (rhi << 8) | (clo << 16) | (chi << 24)))
             wave_off.extend(w.tolist())
             wave_off.append(b - a)
     islands = np.array(islands, dtype=ISLAND_DTYPE) if islands else np.zeros(0, ISLAND_DTYPE)
+    # deepest islands first: one workgroup walks an island's waves in sequence, so the deepest island
+    # is the critical path of the launch (and of the loop-filter rows that wait for it)
+    islands = islands[np.argsort(-islands["n_waves"].astype(np.int64), kind="stable")]
     wave_off = np.array(wave_off if wave_off else [0], np.int32)
     # remainder: global waves
     idx = np.flatnonzero(big)
@@ -465,6 +472,6 @@ def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_fr
                 intra_decode_order=itasks, intra_sorted=itasks_sorted, wave_start=wave_start, n_waves=n_waves,
                 intra_island_tasks=isl_tasks, intra_islands=islands, intra_island_wave_off=isl_wave_off,
                 intra_big_tasks=big_tasks, intra_big_wave_start=big_wave_start,
-                island_rows_expected=island_rows_expected(islands, sb_rows),
+                island_sb_expected=island_sb_expected(islands, sb_rows, sb_cols),
                 lfm=lfm, sb_rows=sb_rows, sb_cols=sb_cols, thresholds=lf_thresholds(sharpness),
                 n_blocks=nb, n_txb=nt)

@@ -187,8 +187,8 @@ typedef struct vp9hip_intra_island {
   uint32_t task_start;
   uint32_t wave_off_start;
   uint32_t n_waves;
-  uint32_t reserved; /* bits 0-15 / 16-31: first / last LUMA superblock row the island's samples lie in
-                        (needed by vp9hip_intra_islands_lf only) */
+  uint32_t reserved; /* the LUMA superblocks the island's samples lie in: first row | last row << 8 | first
+                        column << 16 | last column << 24 (needed by vp9hip_intra_islands_lf only) */
 } vp9hip_intra_island; /* 16 bytes */
 int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
                               const vp9hip_intra_island *d_islands, int n_islands,
@@ -224,15 +224,16 @@ int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_ro
                              int planes /* 1: Y only, 3: Y,U,V */);
 
 /* The island walk and the loop filter of the same frame side by side (HIP streams inside the context):
- * a filter row starts once the islands touching its superblock rows (and the row below, whose intra
- * prediction needs unfiltered neighbours) are done, not when the whole walk is.  h_rows_expected
- * (HOST, sb_rows entries) = number of islands per superblock row, islands[i].reserved = the rows an
- * island touches (vp9hip_pack.h fills both).  Frames with very large components (key frames: the
- * vp9hip_intra_pred_waves remainder) use the two calls in sequence instead.  Ordered after everything
- * enqueued before on the context, and later work is ordered after both kernels. */
+ * the filter takes superblock (r, c) once the islands touching superblocks (r..r+1, c-1..c+1) are done
+ * (an unfinished island there would still read samples the filter changes), not when the whole walk
+ * is.  d_sb_expected (DEVICE, sb_rows * sb_cols entries) = number of islands per superblock,
+ * islands[i].reserved = the superblocks an island touches (vp9hip_pack.h fills both).  Frames with
+ * very large components (key frames: the vp9hip_intra_pred_waves remainder) use the two calls in
+ * sequence instead.  Ordered after everything enqueued before on the context, and later work is
+ * ordered after both kernels.  At most 255 x 255 superblocks. */
 int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks, const vp9hip_intra_island *d_islands,
                             int n_islands, const int32_t *d_wave_off, const int32_t *d_coeffs,
-                            const int32_t *h_rows_expected, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
+                            const int32_t *d_sb_expected, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
                             const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes);
 
 #ifdef __cplusplus

@@ -100,10 +100,11 @@ typedef struct vp9hip_packed {
   int32_t n_islands;
   const int32_t *island_wave_off;
   int32_t n_island_wave_off;
-  /* island i spans luma superblock rows (islands[i].reserved & 0xffff) .. (>> 16);
-   * island_rows_expected[r] = number of islands that touch superblock row r (sb_rows entries) —
-   * what the loop filter of a row waits for when it overlaps the island walk (vp9hip.h) */
-  const int32_t *island_rows_expected;
+  /* islands[i].reserved = the LUMA superblocks the island's samples lie in: first row | last row << 8 |
+   * first column << 16 | last column << 24; island_sb_expected[r * sb_cols + c] = number of islands
+   * that touch superblock (r, c) — what the loop filter waits for, superblock by superblock, when it
+   * runs beside the island walk (vp9hip_intra_islands_lf) */
+  const int32_t *island_sb_expected;
   const vp9hip_intra_task *intra_big_tasks;
   int32_t n_intra_big_tasks;
   const int32_t *big_wave_start; /* n_big_waves + 1 entries */
