@@ -38,6 +38,11 @@ for txs in range(4):
         if bs == 32:
             tasks["y"] = np.repeat(32 + (np.arange(n_isl) % 40) * 34, K)
             tasks["x"] = np.tile(64 + np.arange(K) * bs, n_isl) + np.repeat((np.arange(n_isl) // 40) * (K * bs + 64), K)
+        for i in range(n_isl):
+            t = tasks[i * K:(i + 1) * K]
+            rlo, rhi = int(t["y"].min()) >> 6, (int(t["y"].max()) + bs - 1) >> 6
+            clo, chi = int(t["x"].min()) >> 6, (int(t["x"].max()) + bs - 1) >> 6
+            isl[i]["reserved"] = rlo | (rhi << 8) | (clo << 16) | (chi << 24)
         d_t, d_i, d_w, d_c = ctx.alloc(tasks), ctx.alloc(isl), ctx.alloc(np.array(woff, np.int32)), ctx.alloc(coeffs)
         for it in range(3):
             ctx.intra_pred_islands(d_t, d_i, n_isl, d_w, d_c, frame)
