@@ -265,6 +265,26 @@ static void lf_adjust_mask(const lfm_raw *in, vp9hip_lfm *out, int mi_row, int m
   memcpy(out->lfl_y, in->lfl_y, 64);
 }
 
+int vp9hip_lf_adjust_masks(const vp9hip_lfm *raw, int sb_rows, int sb_cols, int mi_rows, int mi_cols, vp9hip_lfm *out) {
+  if (!raw || !out || sb_rows <= 0 || sb_cols <= 0 || mi_rows <= 0 || mi_cols <= 0 || sb_rows != (mi_rows + 7) >> 3 ||
+      sb_cols != (mi_cols + 7) >> 3)
+    return VP9HIP_EINVAL;
+  for (int r = 0; r < sb_rows; ++r)
+    for (int c = 0; c < sb_cols; ++c) {
+      const vp9hip_lfm *m = &raw[(size_t)r * sb_cols + c];
+      lfm_raw tmp;
+      memcpy(tmp.left_y, m->left_y, sizeof(tmp.left_y));
+      memcpy(tmp.above_y, m->above_y, sizeof(tmp.above_y));
+      tmp.int_4x4_y = m->int_4x4_y;
+      memcpy(tmp.left_uv, m->left_uv, sizeof(tmp.left_uv));
+      memcpy(tmp.above_uv, m->above_uv, sizeof(tmp.above_uv));
+      tmp.int_4x4_uv = m->int_4x4_uv;
+      memcpy(tmp.lfl_y, m->lfl_y, 64);
+      lf_adjust_mask(&tmp, &out[(size_t)r * sb_cols + c], r * 8, c * 8, mi_rows, mi_cols);
+    }
+  return VP9HIP_OK;
+}
+
 void vp9hip_lf_frame_init(int default_lvl, int sharpness, const int32_t seg_enabled[8], const int32_t seg_data[8],
                           int abs_delta, int mode_ref_delta_enabled, const int8_t ref_deltas[4],
                           const int8_t mode_deltas[2], uint8_t out_lvl[8][4][2], vp9hip_lf_thresh *out_thresh) {

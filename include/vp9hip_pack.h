@@ -136,6 +136,12 @@ const char *vp9hip_packer_error(const vp9hip_packer *pk);
 int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *params, const vp9hip_block *blocks,
                       int n_blocks, const vp9hip_coeff_layout *coeffs, vp9hip_packed *out);
 
+/* vp9_adjust_mask (libvpx/vp9/common/vp9_loopfilter.c:766-880) over a frame's masks: `raw` is what
+ * vp9_build_mask accumulated during parsing (cm->lf.lfm as libvpx holds it before loop_filter_rows
+ * adjusts each record in place, :1440-1468), `out` what vp9hip_loop_filter_frame takes.  raw == out is
+ * allowed. */
+int vp9hip_lf_adjust_masks(const vp9hip_lfm *raw, int sb_rows, int sb_cols, int mi_rows, int mi_cols, vp9hip_lfm *out);
+
 /* Loop-filter level table and thresholds of a frame (vp9_loop_filter_frame_init +
  * update_sharpness, vp9_loopfilter.c:212-295).
  *   seg_lvl[s]: INT32_MIN-free encoding: seg_enabled[s] != 0 -> seg_data[s] is the SEG_LVL_ALT_LF

@@ -19,6 +19,7 @@
 
 #include "./vpx_config.h"
 #include "buffers_struct.h"
+#include "vp9/common/vp9_loopfilter.h"
 #include "vp9/common/vp9_onyxc_int.h"
 #include "vp9/decoder/vp9_decoder.h"
 #include "vpx_scale/yv12config.h"
@@ -38,7 +39,13 @@ typedef struct {
   VP9Decoder *pbi;
   BufferPool *pool;
   unsigned int frame_no;
+  int gpu_lf;
 } harness;
+
+static void vp9hip_shim_set_gpu_loop_filter_once(harness *H, VP9Decoder *pbi, int on) {
+  if (H->gpu_lf != on) vp9hip_shim_set_gpu_loop_filter(pbi, on); /* toggling forgets the resident frames */
+  H->gpu_lf = on;
+}
 
 void *shimtest_create(void) {
   harness *h = (harness *)calloc(1, sizeof(*h));
@@ -53,7 +60,8 @@ void shimtest_destroy(void *hp) {
   harness *h = (harness *)hp;
   if (!h) return;
   vp9hip_shim_release(h->pbi);
-  for (int i = 0; i < 4; ++i) vpx_free_frame_buffer(&h->pool->frame_bufs[i].buf);
+  for (int i = 0; i < FRAME_BUFFERS; ++i) vpx_free_frame_buffer(&h->pool->frame_bufs[i].buf);
+  free(h->pbi->common.lf.lfm);
   free(h->pool);
   vpx_free(h->pbi);
   free(h);
@@ -78,12 +86,20 @@ static void *plane_ptr(const YV12_BUFFER_CONFIG *b, int p) {
  *   res[p]                   int64 residual planes (aligned size) for the residual mode
  *   out_planes[p]            receive the delivered frame (aligned size, stride = aligned width)
  *   times[4]                 gpu_copy / gpu_run of the inter and intra wrapper
+ *   opts                     NULL, or 8 ints: [0] GPU loop filter on (vp9hip_shim_set_gpu_loop_filter; the
+ *                            harness then builds cm->lf.lfm with the reference's own vp9_build_mask, one
+ *                            call per block as decode_block does, and the thresholds with
+ *                            vp9_loop_filter_init), [1] sharpness, [2] new_fb_idx, [3..5] frame-buffer index
+ *                            of LAST / GOLDEN / ALTREF, [6] bit k: fill reference k's host buffer from
+ *                            ref_planes (else it keeps what an earlier frame left there), [7] bit k:
+ *                            overwrite reference k's HOST buffer with garbage first (a resident device copy
+ *                            must then be what the wrappers use)
  * Returns 0 or the vpx error code; errbuf gets cm->error.detail.
  */
 int shimtest_frame(void *hp, const int32_t *blocks, int n_blocks, int w, int h, int bd, int hbd, int log2_tile_cols,
                    int lossless, int inter_frame, int coefficient_mode, void *const ref_planes[9], const int ref_w[3],
                    const int ref_h[3], const int32_t *const dq[3], const int32_t *const eob[3], const int64_t *const res[3],
-                   void *const out_planes[3], double times[4], char *errbuf, int errbuf_len) {
+                   void *const out_planes[3], double times[4], char *errbuf, int errbuf_len, const int32_t *opts) {
   harness *H = (harness *)hp;
   VP9Decoder *pbi = H->pbi;
   VP9_COMMON *cm = &pbi->common;
@@ -101,26 +117,32 @@ int shimtest_frame(void *hp, const int32_t *blocks, int n_blocks, int w, int h, 
   cm->frame_type = inter_frame ? INTER_FRAME : KEY_FRAME;
   cm->intra_only = 0;
   cm->current_video_frame = ++H->frame_no;
-  cm->new_fb_idx = 3;
+  const int gpu_lf = opts ? opts[0] : 0;
+  const int new_idx = opts ? opts[2] : 3;
+  cm->new_fb_idx = new_idx;
   cm->error.error_code = VPX_CODEC_OK;
   cm->error.setjmp = 0;
   pbi->mb.lossless = lossless;
-  if (vpx_realloc_frame_buffer(&H->pool->frame_bufs[3].buf, w, h, 1, 1, hbd, VP9_DEC_BORDER_IN_PIXELS, 0, NULL, NULL, NULL)) return -100;
-  YV12_BUFFER_CONFIG *cur = &H->pool->frame_bufs[3].buf;
+  if (vpx_realloc_frame_buffer(&H->pool->frame_bufs[new_idx].buf, w, h, 1, 1, hbd, VP9_DEC_BORDER_IN_PIXELS, 0, NULL, NULL, NULL)) return -100;
+  YV12_BUFFER_CONFIG *cur = &H->pool->frame_bufs[new_idx].buf;
   memset(cur->buffer_alloc, 0x55, cur->frame_size);
   for (int k = 0; k < 3; ++k) {
     cm->frame_refs[k].buf = NULL;
     cm->frame_refs[k].idx = -1;
     if (!inter_frame || ref_w[k] <= 0) continue;
-    YV12_BUFFER_CONFIG *rb = &H->pool->frame_bufs[k].buf;
-    if (vpx_realloc_frame_buffer(rb, ref_w[k], ref_h[k], 1, 1, hbd, VP9_DEC_BORDER_IN_PIXELS, 0, NULL, NULL, NULL)) return -101;
-    memset(rb->buffer_alloc, 0xaa, rb->frame_size);
-    for (int p = 0; p < 3; ++p) {
-      const int pw = p ? rb->uv_width : rb->y_width, ph = p ? rb->uv_height : rb->y_height;
-      copy_plane(plane_ptr(rb, p), p ? rb->uv_stride : rb->y_stride, ref_planes[3 * k + p], pw, pw, ph, bps);
+    const int ridx = opts ? opts[3 + k] : k;
+    YV12_BUFFER_CONFIG *rb = &H->pool->frame_bufs[ridx].buf;
+    if (!opts || ((opts[6] >> k) & 1)) {
+      if (vpx_realloc_frame_buffer(rb, ref_w[k], ref_h[k], 1, 1, hbd, VP9_DEC_BORDER_IN_PIXELS, 0, NULL, NULL, NULL)) return -101;
+      memset(rb->buffer_alloc, 0xaa, rb->frame_size);
+      for (int p = 0; p < 3; ++p) {
+        const int pw = p ? rb->uv_width : rb->y_width, ph = p ? rb->uv_height : rb->y_height;
+        copy_plane(plane_ptr(rb, p), p ? rb->uv_stride : rb->y_stride, ref_planes[3 * k + p], pw, pw, ph, bps);
+      }
     }
+    if (opts && ((opts[7] >> k) & 1)) memset(rb->buffer_alloc, 0x3c, rb->frame_size);
     cm->frame_refs[k].buf = rb;
-    cm->frame_refs[k].idx = k;
+    cm->frame_refs[k].idx = ridx;
   }
 
   /* MODE_INFO + ModeInfoBuf + size_for_mb, as decode_block leaves them (:1226-1233) */
@@ -134,6 +156,15 @@ int shimtest_frame(void *hp, const int32_t *blocks, int n_blocks, int w, int h, 
   const int sb_cols = (cm->mi_cols + 7) >> 3, sb_rows = (cm->mi_rows + 7) >> 3;
   int *size_for_mb = (int *)calloc((size_t)sb_cols * sb_rows + 1, sizeof(int));
   int levels[MAX_SEGMENTS], n_levels = 0;
+  cm->lf.filter_level = gpu_lf ? 32 : 0;
+  cm->lf.sharpness_level = opts ? opts[1] : 0;
+  cm->skip_loop_filter = 0;
+  if (gpu_lf) {
+    vp9_loop_filter_init(cm);  /* lfthr[] from the sharpness */
+    cm->lf.lfm_stride = sb_cols;
+    free(cm->lf.lfm);
+    cm->lf.lfm = (LOOP_FILTER_MASK *)calloc((size_t)sb_rows * sb_cols, sizeof(LOOP_FILTER_MASK));
+  }
   for (int i = 0; i < n_blocks && !rc; ++i) {
     const int32_t *b = blocks + REC * i;
     MODE_INFO *mi = &mis[i];
@@ -182,6 +213,12 @@ int shimtest_frame(void *hp, const int32_t *blocks, int n_blocks, int w, int h, 
     }
     ++size_for_mb[(b[0] >> 3) * sb_cols + (b[1] >> 3)];
   }
+  if (gpu_lf && !rc)
+    for (int i = 0; i < n_blocks; ++i) { /* decode_block, :1238-1241 */
+      const BLOCK_SIZE bs = mis[i].sb_type < BLOCK_8X8 ? BLOCK_8X8 : mis[i].sb_type;
+      vp9_build_mask(cm, &mis[i], MiBuf.mi_row[i], MiBuf.mi_col[i], num_8x8_blocks_wide_lookup[bs],
+                     num_8x8_blocks_high_lookup[bs]);
+    }
 
   /* frameBuf by initBuf's rules (:2242-2270) */
   frameBuf fb;
@@ -208,6 +245,7 @@ int shimtest_frame(void *hp, const int32_t *blocks, int n_blocks, int w, int h, 
       if (res && res[p]) copy_plane(fb.plane_residuals[p], st, res[p], pw, pw, ph, (int)sizeof(tran_high_t));
     }
     vp9hip_shim_attach_frame_buffer(pbi, coefficient_mode ? &fb : NULL);
+    if (opts) vp9hip_shim_set_gpu_loop_filter_once(H, pbi, gpu_lf);
     times[0] = times[1] = times[2] = times[3] = 0.0;
     if (inter_frame)
       wrap_cuda_inter_prediction(w * h, &times[0], &times[1], size_for_mb, &MiBuf, cm, pbi, 1, 1 << log2_tile_cols, fb.residuals);

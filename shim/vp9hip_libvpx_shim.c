@@ -38,6 +38,7 @@
 
 #include "./vpx_config.h"
 #include "buffers_struct.h"
+#include "vp9/common/vp9_loopfilter.h"
 #include "vp9/common/vp9_onyxc_int.h"
 #include "vp9/decoder/vp9_decoder.h"
 #include "vpx_ports/mem.h"
@@ -59,6 +60,15 @@ typedef struct {
   int frame_open;               /* the inter wrapper began this frame and left it on the device */
   unsigned int open_frame_no;
   MODE_INFO **open_mi;
+  /* GPU loop filter + resident references: pool slot i shadows cm->buffer_pool->
+   * frame_bufs[i]; a slot is valid while it holds exactly what the host buffer holds */
+  int gpu_lf;
+  struct {
+    const uint8_t *alloc;
+    int w, h, bd, hbd, valid;
+  } resident[VP9HIP_POOL_SLOTS];
+  vp9hip_lfm *lfm_adj;
+  int lfm_cap;
 } shim_state;
 
 static shim_state g_state[SHIM_MAX_DECODERS];
@@ -99,11 +109,19 @@ void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_
     for (int p = 0; p < 3; ++p) s->dq_start[p] = frameBuffer->dqcoeff[p];
 }
 
+void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable) {
+  shim_state *s = state_of(pbi, &pbi->common);
+  if (!s) return;
+  s->gpu_lf = enable != 0;
+  for (int i = 0; i < VP9HIP_POOL_SLOTS; ++i) s->resident[i].valid = 0;
+}
+
 void vp9hip_shim_release(struct VP9Decoder *pbi) {
   for (int i = 0; i < SHIM_MAX_DECODERS; ++i)
     if (g_state[i].pbi == pbi) {
       vp9hip_decoder_destroy(g_state[i].dec);
       free(g_state[i].blocks);
+      free(g_state[i].lfm_adj);
       memset(&g_state[i], 0, sizeof(g_state[i]));
     }
 }
@@ -131,6 +149,24 @@ static void host_frame(const YV12_BUFFER_CONFIG *b, int bit_depth, vp9hip_host_f
   h->ss_y = b->subsampling_y;
   h->bit_depth = bit_depth;
   h->hbd = hbd;
+}
+
+static int slot_of_cur(const shim_state *s, const VP9_COMMON *cm) { return s->gpu_lf ? cm->new_fb_idx : SLOT_CUR; }
+
+static int is_resident(const shim_state *s, int slot, const YV12_BUFFER_CONFIG *b, int bd) {
+  return s->gpu_lf && slot >= 0 && slot < VP9HIP_POOL_SLOTS && s->resident[slot].valid &&
+         s->resident[slot].alloc == b->buffer_alloc && s->resident[slot].w == b->y_crop_width &&
+         s->resident[slot].h == b->y_crop_height && s->resident[slot].bd == bd &&
+         s->resident[slot].hbd == ((b->flags & YV12_FLAG_HIGHBITDEPTH) != 0);
+}
+
+static void mark_resident(shim_state *s, int slot, const YV12_BUFFER_CONFIG *b, int bd) {
+  s->resident[slot].alloc = b->buffer_alloc;
+  s->resident[slot].w = b->y_crop_width;
+  s->resident[slot].h = b->y_crop_height;
+  s->resident[slot].bd = bd;
+  s->resident[slot].hbd = (b->flags & YV12_FLAG_HIGHBITDEPTH) != 0;
+  s->resident[slot].valid = 1;
 }
 
 /* mode_lf_lut + get_filter_level (libvpx/vp9/common/vp9_loopfilter.c:197-225) */
@@ -273,25 +309,36 @@ int wrap_cuda_inter_prediction(int n, double *gpu_copy, double *gpu_run, int *si
   s->frame_open = 0;
   if (begin_frame(s, cm, pbi, size_for_mb, MiBuf, residuals, NULL)) return -1;
   const double t_begin = now_s();
-  /* the reference re-sends its three references for every frame (inter_cuda_kernel.cu:1073-1079);
-   * only the ones the frame's blocks use travel here */
+  /* the reference re-sends its three references for every frame (inter_cuda_kernel.cu:1073-1079); only
+   * the ones the frame's blocks use travel here, and with the GPU loop filter enabled a reference that
+   * was decoded (or uploaded) earlier is still in its pool slot */
   {
     const vp9hip_packed *pk = vp9hip_decoder_packed(s->dec);
     for (int k = 0; k < 3; ++k) {
       vp9hip_host_frame h;
       if (!((pk->refs_used >> k) & 1)) continue;
-      host_frame(cm->frame_refs[k].buf, (int)cm->bit_depth, &h);
-      SHIM_CHECK(s, cm, vp9hip_decoder_upload(s->dec, k, &h));
-      ref_slot[k] = k;
+      const YV12_BUFFER_CONFIG *rb = cm->frame_refs[k].buf;
+      const int slot = s->gpu_lf ? cm->frame_refs[k].idx : k;
+      if (slot < 0 || slot >= VP9HIP_POOL_SLOTS || (s->gpu_lf && slot == cm->new_fb_idx)) {
+        vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: reference %d has no usable frame buffer index", k);
+        return -1;
+      }
+      if (!is_resident(s, slot, rb, (int)cm->bit_depth)) {
+        host_frame(rb, (int)cm->bit_depth, &h);
+        SHIM_CHECK(s, cm, vp9hip_decoder_upload(s->dec, slot, &h));
+        if (s->gpu_lf) mark_resident(s, slot, rb, (int)cm->bit_depth);
+      }
+      ref_slot[k] = slot;
     }
   }
-  SHIM_CHECK(s, cm, vp9hip_decoder_alloc_slot(s->dec, SLOT_CUR, cm->width, cm->height, cm->subsampling_x, (int)cm->bit_depth,
-                                              (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0, 1));
+  if (s->gpu_lf) s->resident[slot_of_cur(s, cm)].valid = 0;
+  SHIM_CHECK(s, cm, vp9hip_decoder_alloc_slot(s->dec, slot_of_cur(s, cm), cm->width, cm->height, cm->subsampling_x,
+                                              (int)cm->bit_depth, (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0, 1));
   const double t1 = now_s();
   if (getenv("VP9HIP_SHIM_TRACE"))
     fprintf(stderr, "vp9hip shim: inter wrapper: pack + lists + coefficients %.2f ms, references + frame slot %.2f ms\n",
             (t_begin - t0) * 1e3, (t1 - t_begin) * 1e3);
-  SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, VP9HIP_PHASE_INTER, ref_slot, SLOT_CUR, NULL, NULL));
+  SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, VP9HIP_PHASE_INTER, ref_slot, slot_of_cur(s, cm), NULL, NULL));
   SHIM_CHECK(s, cm, vp9hip_decoder_sync(s->dec));
   SHIM_CHECK(s, cm, vp9hip_decoder_last_run_ms(s->dec, &ms));
   /* the frame stays on the device: wrap_cuda_intra_prediction runs next on the same frame
@@ -319,19 +366,59 @@ int wrap_cuda_intra_prediction(double *gpu_copy, double *gpu_run, int *size_for_
   if (!(s->frame_open && s->open_frame_no == cm->current_video_frame && s->open_mi == MiBuf->mi)) {
     /* key / intra-only frame path of the caller: the inter wrapper was not called */
     if (begin_frame(s, cm, pbi, size_for_mb, MiBuf, NULL, frameBuffer)) return -1;
-    SHIM_CHECK(s, cm, vp9hip_decoder_alloc_slot(s->dec, SLOT_CUR, cm->width, cm->height, cm->subsampling_x,
+    if (s->gpu_lf) s->resident[slot_of_cur(s, cm)].valid = 0;
+    SHIM_CHECK(s, cm, vp9hip_decoder_alloc_slot(s->dec, slot_of_cur(s, cm), cm->width, cm->height, cm->subsampling_x,
                                                 (int)cm->bit_depth, (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0, 1));
   }
   s->frame_open = 0;
+  /* phase E on the GPU (vp9hip_shim_set_gpu_loop_filter): libvpx's own masks, adjusted the way
+   * loop_filter_rows does before filtering a superblock (vp9_loopfilter.c:1440-1468), and its threshold
+   * table; the island walk and the filter then run side by side */
+  int phases = VP9HIP_PHASE_INTRA;
+  const vp9hip_lfm *h_lfm = NULL;
+  vp9hip_lf_thresh th;
+  if (s->gpu_lf && cm->lf.filter_level && !cm->skip_loop_filter) {
+    const int sb_rows = (cm->mi_rows + 7) >> 3, sb_cols = (cm->mi_cols + 7) >> 3;
+    if (sizeof(LOOP_FILTER_MASK) != sizeof(vp9hip_lfm)) {
+      vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: LOOP_FILTER_MASK layout differs");
+      return -1;
+    }
+    if (sb_rows * sb_cols > s->lfm_cap) {
+      free(s->lfm_adj);
+      s->lfm_cap = sb_rows * sb_cols;
+      s->lfm_adj = (vp9hip_lfm *)malloc(sizeof(vp9hip_lfm) * (size_t)s->lfm_cap);
+      if (!s->lfm_adj) {
+        s->lfm_cap = 0;
+        vpx_internal_error(&cm->error, VPX_CODEC_MEM_ERROR, "vp9hip shim: out of memory");
+        return -1;
+      }
+    }
+    for (int r = 0; r < sb_rows; ++r)
+      memcpy(&s->lfm_adj[(size_t)r * sb_cols], &cm->lf.lfm[(size_t)r * cm->lf.lfm_stride], sizeof(vp9hip_lfm) * (size_t)sb_cols);
+    if (vp9hip_lf_adjust_masks(s->lfm_adj, sb_rows, sb_cols, cm->mi_rows, cm->mi_cols, s->lfm_adj) != VP9HIP_OK) {
+      vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: bad loop-filter mask geometry");
+      return -1;
+    }
+    for (int l = 0; l < 64; ++l) {
+      th.mblim[l] = cm->lf_info.lfthr[l].mblim[0];
+      th.lim[l] = cm->lf_info.lfthr[l].lim[0];
+      th.hev_thr[l] = cm->lf_info.lfthr[l].hev_thr[0];
+    }
+    h_lfm = s->lfm_adj;
+    phases |= VP9HIP_PHASE_LF;
+  }
   t_copy += now_s() - t0;
-  SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, VP9HIP_PHASE_INTRA, ref_slot, SLOT_CUR, NULL, NULL));
+  SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, phases, ref_slot, slot_of_cur(s, cm), h_lfm, h_lfm ? &th : NULL));
   SHIM_CHECK(s, cm, vp9hip_decoder_sync(s->dec));
   SHIM_CHECK(s, cm, vp9hip_decoder_last_run_ms(s->dec, &ms));
   /* the reference's contract: the reconstructed frame is in the host buffer on return, because the
-   * CPU loop filter runs next (vp9_decodeframe.c:2585; intra_cuda_kernel.cu:1368) */
+   * CPU loop filter runs next (vp9_decodeframe.c:2585; intra_cuda_kernel.cu:1368).  With the GPU loop
+   * filter the delivered frame is already filtered (the caller drops phase E) and the device copy
+   * stays valid as a reference for later frames. */
   t0 = now_s();
   host_frame(cur, (int)cm->bit_depth, &h);
-  SHIM_CHECK(s, cm, vp9hip_decoder_download(s->dec, SLOT_CUR, &h));
+  SHIM_CHECK(s, cm, vp9hip_decoder_download(s->dec, slot_of_cur(s, cm), &h));
+  if (s->gpu_lf) mark_resident(s, slot_of_cur(s, cm), cur, (int)cm->bit_depth);
   t_copy += now_s() - t0;
   if (gpu_copy) *gpu_copy = t_copy;
   if (gpu_run) *gpu_run = (double)ms * 1e-3;

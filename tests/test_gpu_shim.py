@@ -98,6 +98,25 @@ def _residual_planes(oracle, L, allc, dims, bd, lossless):
     return res
 
 
+def _call(harness, h, recs, W, H, bd, tiles, lossless, inter, coefficient_mode, refs, ref_sizes, coef, eob, res, got, opts=None):
+    flat_refs = [a for r in refs for a in r]
+    ref_ptrs = (ctypes.c_void_p * 9)(*[a.ctypes.data for a in flat_refs])
+    rw = (ctypes.c_int * 3)(*[s[0] for s in ref_sizes])
+    rh = (ctypes.c_int * 3)(*[s[1] for s in ref_sizes])
+    dq = (ctypes.c_void_p * 3)(*[c.ctypes.data if len(c) else None for c in coef])
+    eob_keep = [np.ascontiguousarray(e) for e in eob]
+    eobp = (ctypes.c_void_p * 3)(*[e.ctypes.data for e in eob_keep])
+    resp = (ctypes.c_void_p * 3)(*[r.ctypes.data for r in res]) if res is not None else None
+    outp = (ctypes.c_void_p * 3)(*[g.ctypes.data for g in got])
+    times = (ctypes.c_double * 4)()
+    err = ctypes.create_string_buffer(512)
+    o = (ctypes.c_int32 * 8)(*opts) if opts is not None else None
+    rc = harness.shimtest_frame(ctypes.c_void_p(h), recs.ctypes.data_as(ctypes.c_void_p), len(recs), W, H, bd, int(bd > 8),
+                                tiles, int(lossless), int(inter), int(coefficient_mode), ref_ptrs, rw, rh, dq, eobp, resp,
+                                outp, times, err, 512, o)
+    return rc, err.value.decode(), list(times)
+
+
 def _run(harness, hip, oracle, W, H, bd, seed, *, inter=True, coefficient_mode=True, tiles=0, lossless=False,
          ref_sizes=None, gen_kw=None):
     rng = np.random.default_rng(seed)
@@ -121,23 +140,10 @@ def _run(harness, hip, oracle, W, H, bd, seed, *, inter=True, coefficient_mode=T
     recs = blockgen.to_ref_records(blocks)
     got = [np.zeros((d[1], d[0]), dt) for d in dims]
     h = harness.shimtest_create()
-    flat_refs = [a for r in refs for a in r]
-    ref_ptrs = (ctypes.c_void_p * 9)(*[a.ctypes.data for a in flat_refs])
-    rw = (ctypes.c_int * 3)(*[s[0] for s in ref_sizes])
-    rh = (ctypes.c_int * 3)(*[s[1] for s in ref_sizes])
-    dq = (ctypes.c_void_p * 3)(*[c.ctypes.data if len(c) else None for c in coef])
-    eobp = (ctypes.c_void_p * 3)(*[np.ascontiguousarray(e).ctypes.data for e in eob])
-    eob_keep = [np.ascontiguousarray(e) for e in eob]
-    eobp = (ctypes.c_void_p * 3)(*[e.ctypes.data for e in eob_keep])
-    resp = (ctypes.c_void_p * 3)(*[r.ctypes.data for r in res]) if res is not None else None
-    outp = (ctypes.c_void_p * 3)(*[g.ctypes.data for g in got])
-    times = (ctypes.c_double * 4)()
-    err = ctypes.create_string_buffer(512)
-    rc = harness.shimtest_frame(ctypes.c_void_p(h), recs.ctypes.data_as(ctypes.c_void_p), len(recs), W, H, bd, int(bd > 8),
-                                tiles, int(lossless), int(inter), int(coefficient_mode), ref_ptrs, rw, rh, dq, eobp, resp,
-                                outp, times, err, 512)
+    rc, err, times = _call(harness, h, recs, W, H, bd, tiles, lossless, inter, coefficient_mode, refs, ref_sizes, coef, eob,
+                           res, got)
     harness.shimtest_destroy(ctypes.c_void_p(h))
-    return rc, err.value.decode(), got, expect, list(times), L
+    return rc, err, got, expect, times, L
 
 
 def blockgen_noise(rng, h, w, bd):
@@ -185,3 +191,65 @@ def test_residual_plane_mode_refuses_8bit_frames(harness, hip, oracle):
     rc, err, *_ = _run(harness, hip, oracle, 128, 128, 8, seed=5, coefficient_mode=False)
     assert rc != 0
     assert "high-bitdepth" in err
+
+
+def _lf_oracle(hip, oracle, planes, L, dims, bd, sharp):
+    """Loop filter of `planes` in place through the oracle, masks from the C packer (pinned equal to
+    vp9_build_mask + vp9_adjust_mask), thresholds from vp9hip_lf_frame_init (pinned equal to libvpx's)."""
+    from frame_check import OThresh
+    th = hip.LfThresh()
+    hip.lib().vp9hip_lf_frame_init(32, sharp, None, None, 0, 0, None, None, None, ctypes.byref(th))
+    oth = OThresh.from_buffer_copy(bytes(th))
+    PAD = 16
+    bufs = [np.zeros((d[1] + PAD, d[0] + PAD), planes[0].dtype) for d in dims]
+    for b, p in zip(bufs, planes):
+        b[:p.shape[0], :p.shape[1]] = p
+    ptrs = (ctypes.c_void_p * 3)(*[b.ctypes.data for b in bufs])
+    strides = (ctypes.c_int * 3)(*[b.shape[1] for b in bufs])
+    oracle.vp9o_loop_filter_frame(L["lfm"].ctypes.data_as(ctypes.c_void_p), L["sb_rows"], L["sb_cols"], ctypes.byref(oth),
+                                  ptrs, strides, dims[0][1] // 8, bd, int(bd > 8), 3)
+    return [b[:d[1], :d[0]].copy() for b, d in zip(bufs, dims)]
+
+
+@pytest.mark.parametrize("W,H,bd,sharp", [(352, 288, 8, 0), (330, 250, 10, 4), (640, 360, 8, 0)])
+def test_gpu_loop_filter_and_resident_references_through_the_wrappers(harness, hip, oracle, W, H, bd, sharp):
+    """vp9hip_shim_set_gpu_loop_filter: the intra wrapper also runs phase E — masks built by the reference's
+    own vp9_build_mask (harness), adjusted and filtered on the GPU — and the decoded frame stays in the device
+    pool: the next frame references it while the HOST copy of that buffer is overwritten with garbage."""
+    rng = np.random.default_rng(W + bd)
+    dt = np.uint16 if bd > 8 else np.uint8
+    dims, crop = _dims(W, H)
+    sizes = [(W, H)] * 3
+    refs = [[np.ascontiguousarray(blockgen_noise(rng, d[1], d[0], bd)).astype(dt) for d in dims] for _ in range(3)]
+    h = harness.shimtest_create()
+    # ---- frame A into frame buffer 5, references uploaded from buffers 0, 1, 2
+    blocksA = blockgen.gen_blocks(rng, W, H, hip.BLOCK_DTYPE, levels=(0, 10, 32, 50))
+    coefA, eobA = blockgen.gen_coeffs(rng, blocksA, W, H, bd)
+    preA, LA, _ = _expected(hip, oracle, blocksA, W, H, bd, sizes, refs, coefA, eobA, 0, 0)
+    P = hip.FrameParams()
+    P.width, P.height, P.ss_x, P.ss_y, P.bit_depth, P.hbd, P.build_lf_masks = W, H, 1, 1, bd, int(bd > 8), 1
+    for k in range(3):
+        P.ref_width[k], P.ref_height[k] = W, H
+    pk = hip.Packer()
+    LmA = pk.pack(P, blocksA, eobA)
+    expA = _lf_oracle(hip, oracle, preA, LmA, dims, bd, sharp)
+    gotA = [np.zeros((d[1], d[0]), dt) for d in dims]
+    rc, err, _ = _call(harness, h, blockgen.to_ref_records(blocksA), W, H, bd, 0, False, True, True, refs, sizes, coefA, eobA,
+                       None, gotA, opts=(1, sharp, 5, 0, 1, 2, 7, 0))
+    assert rc == 0, err
+    _assert_equal(gotA, expA)
+    assert any((a != b).any() for a, b in zip(expA, preA))  # the filter did change the frame
+    # ---- frame B into buffer 6: LAST = buffer 5 (frame A, NOT re-filled, host copy poisoned), GOLDEN = 1
+    blocksB = blockgen.gen_blocks(rng, W, H, hip.BLOCK_DTYPE, intra_frac=0.1, levels=(0, 20, 40))
+    coefB, eobB = blockgen.gen_coeffs(rng, blocksB, W, H, bd)
+    refsB = [expA, refs[1], refs[2]]
+    preB, LB, _ = _expected(hip, oracle, blocksB, W, H, bd, sizes, refsB, coefB, eobB, 0, 0)
+    LmB = pk.pack(P, blocksB, eobB)
+    expB = _lf_oracle(hip, oracle, preB, LmB, dims, bd, sharp)
+    gotB = [np.zeros((d[1], d[0]), dt) for d in dims]
+    rc, err, _ = _call(harness, h, blockgen.to_ref_records(blocksB), W, H, bd, 0, False, True, True, refsB, sizes, coefB, eobB,
+                       None, gotB, opts=(1, sharp, 6, 5, 1, 2, 0b110, 0b001))
+    assert rc == 0, err
+    _assert_equal(gotB, expB)
+    pk.close()
+    harness.shimtest_destroy(ctypes.c_void_p(h))

@@ -38,10 +38,13 @@ if not coefficient_mode:
 resp = (ctypes.c_void_p * 3)(*[r.ctypes.data for r in res]) if res else None
 outp = (ctypes.c_void_p * 3)(*[x.ctypes.data for x in got])
 times = (ctypes.c_double * 4)(); err = ctypes.create_string_buffer(512)
+gpu_lf = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+# opts: GPU loop filter, sharpness, new_fb_idx, LAST/GOLDEN/ALTREF buffer indices, fill mask, poison mask
+opts = (ctypes.c_int32 * 8)(gpu_lf, 0, 3, 0, 1, 2, 7, 0)
 for it in range(6):
     t0 = time.perf_counter()
     rc = lib.shimtest_frame(ctypes.c_void_p(h), recs.ctypes.data_as(ctypes.c_void_p), len(recs), W, H, bd, int(bd > 8), 2, 0, 1,
-                            coefficient_mode, ref_ptrs, rw, rh, dq, eobp, resp, outp, times, err, 512)
+                            coefficient_mode, ref_ptrs, rw, rh, dq, eobp, resp, outp, times, err, 512, opts)
     wall = time.perf_counter() - t0
     assert rc == 0, err.value
     print(f"frame {it}: inter copy {times[0]*1e3:.2f} ms run {times[1]*1e3:.3f} ms | intra copy {times[2]*1e3:.2f} ms run {times[3]*1e3:.3f} ms"
