@@ -483,11 +483,11 @@ __device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9h
 }
 
 
-// Three-wave form of the row walk: wave 0 filters, wave 1 moves data in, wave 2 hands rows to the
-// row below.  Per superblock c:
+// Four-wave form of the row walk: wave 0 filters, wave 1 moves data in, wave 2 hands rows to the
+// row below, wave 3 writes the finished superblock back.  Per superblock c:
 //   phase A   wave 0: vertical pass of c, LDS flag.
-//             wave 1: bulk write-back of c-1, then waits for the row above and brings its bottom
-//             8 rows into tile rows 0..7 (which the vertical pass does not touch).
+//             wave 1: waits for the row above and brings its bottom 8 rows into tile rows 0..7
+//             (which the vertical pass does not touch).  wave 3: bulk write-back of c-1.
 //             wave 2: on the flag, the 8x8 corner that pass completed (bottom rows of the PREVIOUS
 //             superblock's last 8 columns) goes out write-through; drained; v-progress = c+1.
 //   phase B   wave 0: horizontal pass of c, LDS flag, right strip -> left strip of the other buffer.
@@ -669,8 +669,9 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) flags[0] = sc + 1;
     } else if (wave == 1) {
-      if (sc > 0) bulk_writeback(sc - 1);
       fetch_above(sc);
+    } else if (wave == 3) {
+      if (sc > 0) bulk_writeback(sc - 1);  // its own wave: twice the bytes with 16-bit samples
     } else {
       wait_flag(&flags[0], sc + 1);
       if (sc > 0) handoff(t32, x0, 0, 8);  // the corner the vertical pass completed (drained)
@@ -695,18 +696,18 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         load_interior(sc + 1);
         store_interior(sc + 1);
       }
-    } else {
+    } else if (wave == 2) {
       wait_flag(&flags[1], sc + 1);
       handoff(t32, x0, 8, last ? n + 8 : n);
       if (lane == 0) __hip_atomic_store(hprog_mine, last ? sb_cols : sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
-  if (wave == 1) bulk_writeback(ncols - 1);
+  if (wave == 3) bulk_writeback(ncols - 1);
 }
 
 template <typename Pix>
-__global__ __launch_bounds__(192) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
+__global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                                        LfThreshDev th, FrameDev f, int mi_rows, int *progress,
                                                        int *err, const int *gate_done, const int *gate_expected) {
   __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
@@ -772,10 +773,10 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
     ctx->lf_err_flag = err;
     if (mode == 2) {
       if (frame->hbd)
-        hipLaunchKernelGGL(lf_rows2_kernel<uint16_t>, dim3(sb_rows, planes), dim3(192), 0, st, d_lfm, sb_cols,
+        hipLaunchKernelGGL(lf_rows2_kernel<uint16_t>, dim3(sb_rows, planes), dim3(256), 0, st, d_lfm, sb_cols,
                            sb_rows, th, f, mi_rows, progress, err, d_gate, d_sb_expected);
       else
-        hipLaunchKernelGGL(lf_rows2_kernel<uint8_t>, dim3(sb_rows, planes), dim3(192), 0, st, d_lfm, sb_cols,
+        hipLaunchKernelGGL(lf_rows2_kernel<uint8_t>, dim3(sb_rows, planes), dim3(256), 0, st, d_lfm, sb_cols,
                            sb_rows, th, f, mi_rows, progress, err, d_gate, d_sb_expected);
     } else if (frame->hbd)
       hipLaunchKernelGGL(lf_rows_kernel<uint16_t>, dim3(sb_rows, planes), dim3(64), 0, st, d_lfm, sb_cols,
