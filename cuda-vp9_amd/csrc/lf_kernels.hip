@@ -5,8 +5,9 @@
 // columns [64c-8, 64c+63] (vertical pass, rows of SB row r) and rows [64r-8, 64r+63]
 // (horizontal pass, columns of SB column c), so it must run after (r,c-1) and (r-1,c+1) —
 // libvpx's own row-MT sync rule (vp9_thread_common.c:38-55).  All superblocks with the same
-// t = c + 2r are independent: one launch per anti-diagonal t, one wavefront per
-// (superblock, plane).
+// t = c + 2r are independent: the first form here (lf_diag_kernel, VP9HIP_LF_MODE=diag) is one launch
+// per anti-diagonal t, one wavefront per (superblock, plane); the default is the row walk further
+// down (lf_rows2_kernel): one launch, a workgroup per (superblock row, plane), rows pipelined.
 //
 // Inside a superblock plane the 64 (32) pixel rows are independent in the vertical pass and
 // the 64 (32) columns in the horizontal pass: lane = row, then lane = column.  Each lane walks
@@ -757,7 +758,7 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
   memcpy(&th, h_thresh, sizeof(th));
   const FrameDev f = to_dev(frame);
   const int mi_rows = frame->aheight[0] / 8;
-  static int mode = -1;  // 0: one launch per anti-diagonal, 1: row walk (1 wave), 2: row walk (3 waves)
+  static int mode = -1;  // 0: one launch per anti-diagonal, 1: row walk (1 wave), 2: row walk (4 waves, the default)
   if (mode < 0) {
     const char *e = getenv("VP9HIP_LF_MODE");
     mode = (e && !strcmp(e, "diag")) ? 0 : (e && !strcmp(e, "rows")) ? 1 : 2;

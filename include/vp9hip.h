@@ -201,8 +201,8 @@ int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
  * vp9_adjust_mask) and the per-level threshold table (loop_filter_info_n.lfthr,
  * vp9_loopfilter.h:53-58).  The filter order is libvpx's: superblocks in raster order, per
  * superblock and plane all vertical edges then all horizontal ones (vp9_loopfilter.c:1424-
- * 1469, 1241-1422); on the GPU superblocks run on the anti-diagonal wavefront that keeps
- * exactly that order where pixels overlap.
+ * 1469, 1241-1422); on the GPU one workgroup walks each superblock row, rows pipelined behind
+ * each other, which keeps exactly that order where pixels overlap.
  * ---------------------------------------------------------------------------------------- */
 typedef struct vp9hip_lfm {
   uint64_t left_y[4];  /* per TX_SIZE */
