@@ -16,15 +16,17 @@ __device__ __forceinline__ int clip_pix(int v, int maxv) {
   return v < 0 ? 0 : (v > maxv ? maxv : v);
 }
 
+constexpr int TX_LDS_INTS = (256 / 32) * 32 * 33;  // the 32x32 class needs the most: 8 blocks x 32 rows x 33 dwords
+
 template <int N, typename Pix, bool HBD>
-__global__ __launch_bounds__(256) void idct_add_kernel(const vp9hip_txb *__restrict__ blocks, int n_blocks,
-                                                       const int32_t *__restrict__ coeffs, FrameDev f) {
+__device__ __forceinline__ void idct_add_body(int *lds, int wg, const vp9hip_txb *__restrict__ blocks, int n_blocks,
+                                              const int32_t *__restrict__ coeffs, const FrameDev &f) {
   constexpr int BPW = 256 / N;          // blocks per workgroup
   constexpr int PITCH = N + 1;          // LDS row pitch in dwords
-  __shared__ int lds[BPW * N * PITCH];
+  static_assert(BPW * N * PITCH <= TX_LDS_INTS, "LDS budget");
   const int t = threadIdx.x % N;        // lane inside the block
   const int lb = threadIdx.x / N;       // local block
-  const int gb = blockIdx.x * BPW + lb;
+  const int gb = wg * BPW + lb;
   const bool active = gb < n_blocks;
   int *tile = lds + lb * N * PITCH;
 
@@ -108,18 +110,27 @@ __global__ __launch_bounds__(256) void idct_add_kernel(const vp9hip_txb *__restr
     if (k < rows) p[(size_t)k * stride] = (Pix)clip_pix<Pix>(txfm::add32(d[k], v[k]), maxv);
 }
 
-template <int N>
-int launch_size(vp9hip_ctx *ctx, const vp9hip_txb *blocks, int n, const int32_t *coeffs, const vp9hip_frame *fr) {
-  if (n <= 0) return VP9HIP_OK;
-  constexpr int BPW = 256 / N;
-  const int grid = (n + BPW - 1) / BPW;
-  const FrameDev f = to_dev(fr);
-  if (fr->hbd)
-    hipLaunchKernelGGL((idct_add_kernel<N, uint16_t, true>), dim3(grid), dim3(256), 0, ctx->stream, blocks, n, coeffs, f);
+// All four transform sizes in one launch: workgroups [wg_start[k], wg_start[k+1]) serve size class k
+// (the four launches were 7-10 us each for a 1440p frame, back to back and each with its own tail).
+struct TxPlan {
+  int wg_start[5];
+  int blk_start[4];
+  int count[4];
+};
+
+template <typename Pix, bool HBD>
+__global__ __launch_bounds__(256) void idct_add_all_kernel(const vp9hip_txb *__restrict__ blocks, TxPlan plan,
+                                                           const int32_t *__restrict__ coeffs, FrameDev f) {
+  __shared__ int lds[TX_LDS_INTS];
+  const int b = blockIdx.x;
+  if (b < plan.wg_start[1])
+    idct_add_body<4, Pix, HBD>(lds, b - plan.wg_start[0], blocks + plan.blk_start[0], plan.count[0], coeffs, f);
+  else if (b < plan.wg_start[2])
+    idct_add_body<8, Pix, HBD>(lds, b - plan.wg_start[1], blocks + plan.blk_start[1], plan.count[1], coeffs, f);
+  else if (b < plan.wg_start[3])
+    idct_add_body<16, Pix, HBD>(lds, b - plan.wg_start[2], blocks + plan.blk_start[2], plan.count[2], coeffs, f);
   else
-    hipLaunchKernelGGL((idct_add_kernel<N, uint8_t, false>), dim3(grid), dim3(256), 0, ctx->stream, blocks, n, coeffs, f);
-  VP9HIP_CHECK(ctx, hipGetLastError());
-  return VP9HIP_OK;
+    idct_add_body<32, Pix, HBD>(lds, b - plan.wg_start[3], blocks + plan.blk_start[3], plan.count[3], coeffs, f);
 }
 
 }  // namespace
@@ -132,14 +143,25 @@ extern "C" int vp9hip_idct_add_batch(vp9hip_ctx *ctx, const vp9hip_txb *d_blocks
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_idct_add_batch: bad argument");
   for (int i = 0; i < 4; ++i)
     if (size_count[i] < 0) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_idct_add_batch: negative count");
-  int rc;
-  const vp9hip_txb *b = d_blocks;
-  if ((rc = launch_size<4>(ctx, b, size_count[0], d_coeffs, frame))) return rc;
-  b += size_count[0];
-  if ((rc = launch_size<8>(ctx, b, size_count[1], d_coeffs, frame))) return rc;
-  b += size_count[1];
-  if ((rc = launch_size<16>(ctx, b, size_count[2], d_coeffs, frame))) return rc;
-  b += size_count[2];
-  if ((rc = launch_size<32>(ctx, b, size_count[3], d_coeffs, frame))) return rc;
+  TxPlan plan;
+  int acc_w = 0, acc_b = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int bpw = 256 / (4 << k);
+    plan.wg_start[k] = acc_w;
+    plan.blk_start[k] = acc_b;
+    plan.count[k] = size_count[k];
+    acc_w += (size_count[k] + bpw - 1) / bpw;
+    acc_b += size_count[k];
+  }
+  plan.wg_start[4] = acc_w;
+  if (acc_w == 0) return VP9HIP_OK;
+  const FrameDev f = to_dev(frame);
+  // the 32x32 class first in the grid would start the longest workgroups first, but the classes are
+  // laid out 4x4 .. 32x32 like the record list; the grid is short enough (a few rounds) for this not to matter
+  if (frame->hbd)
+    hipLaunchKernelGGL((idct_add_all_kernel<uint16_t, true>), dim3(acc_w), dim3(256), 0, ctx->stream, d_blocks, plan, d_coeffs, f);
+  else
+    hipLaunchKernelGGL((idct_add_all_kernel<uint8_t, false>), dim3(acc_w), dim3(256), 0, ctx->stream, d_blocks, plan, d_coeffs, f);
+  VP9HIP_CHECK(ctx, hipGetLastError());
   return VP9HIP_OK;
 }
