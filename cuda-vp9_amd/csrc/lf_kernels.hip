@@ -746,7 +746,7 @@ __global__ __launch_bounds__(64) void lf_rows_kernel(const vp9hip_lfm *__restric
 
 static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
                      const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes, const int *d_gate,
-                     const int32_t *d_sb_expected) {
+                     const int32_t *d_sb_expected, bool counters_zeroed = false) {
   if (!d_lfm || sb_rows <= 0 || sb_cols <= 0 || !h_thresh || !frame_ok(frame) || (planes != 1 && planes != 3))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_loop_filter_frame: bad argument");
   if (sb_rows != (frame->aheight[0] + 63) / 64 || sb_cols != (frame->awidth[0] + 63) / 64)
@@ -770,7 +770,7 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
     int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
     if (rc) return rc;
     int *progress = (int *)ctx->scratch, *err = progress + 6 * sb_rows;
-    VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, st));
+    if (!counters_zeroed) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, st));
     ctx->lf_err_flag = err;
     if (mode == 2) {
       if (frame->hbd)
@@ -838,21 +838,23 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
     VP9HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_gate, VP9HIP_GATE_INTS * sizeof(int)));
   }
-  // scratch for the filter's progress counters must exist before the fork (growing it synchronises)
+  // one zero-fill for the filter's progress counters and the island counters behind them (scratch must
+  // exist before the fork: growing it synchronises)
+  const size_t lf_ints = (size_t)(6 * sb_rows + 1);
+  const size_t gate_off = (lf_ints + 63) & ~(size_t)63;
+  const size_t need = (gate_off + (size_t)sb_rows * sb_cols) * sizeof(int);
   {
-    const size_t need = (size_t)(6 * sb_rows + 1) * sizeof(int);
     int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
     if (rc) return rc;
   }
-  VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->d_gate, 0, (size_t)sb_rows * sb_cols * sizeof(int), ctx->stream));
+  int *d_gate = (int *)ctx->scratch + gate_off;
+  VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
   VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   VP9HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  int rc = vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, ctx->d_gate,
-                                 sb_cols);
+  int rc = vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, d_gate, sb_cols);
   if (rc) return rc;
-  rc = lf_launch(ctx, ctx->stream2, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, ctx->d_gate, d_sb_expected);
+  rc = lf_launch(ctx, ctx->stream2, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, d_gate, d_sb_expected, true);
   // join even if the filter launch failed, so that the context's stream stays ordered
   (void)hipEventRecord(ctx->ev_join, ctx->stream2);
   (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);

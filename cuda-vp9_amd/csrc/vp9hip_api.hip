@@ -42,7 +42,6 @@ extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->d_taps) (void)hipFree(ctx->d_taps);
-  if (ctx->d_gate) (void)hipFree(ctx->d_gate);
   if (ctx->stream2) {
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipEventDestroy(ctx->ev_fork);

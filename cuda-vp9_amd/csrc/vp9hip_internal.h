@@ -23,7 +23,6 @@ struct vp9hip_ctx {
   // overlap of the intra island walk with the loop filter (vp9hip_intra_islands_lf)
   hipStream_t stream2;
   hipEvent_t ev_fork, ev_join;
-  int *d_gate;  // islands done per superblock (VP9HIP_GATE_INTS counters)
 };
 
 #define VP9HIP_FAIL(ctx, code, ...)                          \
