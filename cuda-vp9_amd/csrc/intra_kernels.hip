@@ -212,7 +212,13 @@ __device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t,
 }
 
 // Up to SLOTS (8) independent transform blocks, one per 32-lane slot.  `active` slots predict (and
-// add the residual of) tasks[index]; every thread of the workgroup must call this (barriers).
+// add the residual of) tasks[index]; every thread of the workgroup calls this.
+// A block's slot (32 lanes) lies inside one wavefront and edge[] / tiles[] of a slot are touched by that
+// slot only; a wave's LDS operations execute in issue order.  The stages of a chunk therefore need the
+// compiler pinned and lgkmcnt drained, not a workgroup barrier (which made the four waves of an island
+// wait for the slowest one, twice per chunk, and drained its global stores as well).
+__device__ __forceinline__ void slot_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local"); }
+
 template <typename Pix, bool HBD>
 __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 * TPITCH],
                                             const vp9hip_intra_task *__restrict__ tasks, int index, bool active,
@@ -283,7 +289,7 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
         for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = src[i * bs + t];
     }
   }
-  __syncthreads();
+  slot_sync();
   if (coded && !dc_kind && !identity && t < bs) {
     const int tt = tk.tx_type & 3;
     switch (tk.tx_size) {
@@ -293,7 +299,7 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
       default: row_pass<32, HBD>(tile, t, 0, false); break;
     }
   }
-  __syncthreads();
+  slot_sync();
   if (active) {
     switch (tk.tx_size) {
       case 0: finish_block<4, Pix, HBD>(tk, t, E, tile, coded, dc_coeff, dc_kind, f); break;
