@@ -83,6 +83,9 @@ def _oracle_frame(hip, oracle, P, blocks, coef, eob, refs, W, H, bd, th):
     (1280, 720, 8, 2, 0, dict(levels=(0, 8, 30, 63))),
     (256, 256, 8, 0, 0, dict(all_intra=True)),
     (2560, 1440, 8, 3, 0, dict(intra_frac=0.08)),   # BASELINE.json's frame size, 8 tile columns
+    (8, 8, 8, 0, 0, dict(intra_frac=0.5)),          # one 8x8 block: every edge is a frame edge
+    (24, 40, 10, 0, 2, dict(intra_frac=0.3)),
+    (72, 16, 8, 0, 0, {}),
 ])
 def test_decoder_three_phases_match_oracle(hip, oracle, W, H, bd, tiles, sharp, kw):
     import cuda_vp9_amd.workload as workload
