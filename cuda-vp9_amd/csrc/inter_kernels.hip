@@ -155,8 +155,11 @@ __device__ __forceinline__ int dot8(unsigned lo, unsigned hi, unsigned flo, unsi
   // 16384 = 128 * sum(taps) undoes the -128 bias of the samples; 64 = rounding
   int s = __builtin_amdgcn_sdot4((int)lo, (int)flo, 16384 + 64, false);
   s = __builtin_amdgcn_sdot4((int)hi, (int)fhi, s, false);
-  s >>= 7;
-  return s < 0 ? 0 : (s > 255 ? 255 : s);
+  // clip_pixel(s >> 7), with the clamp BEFORE the shift: clamp-after-shift of two results that are then
+  // packed gets selected as v_ashr_pk_u8_i32, whose destination's upper half did not come out zero on
+  // the MI355X under test (the packed dwords of the register path had garbage in bytes 2-3)
+  s = s < 0 ? 0 : (s > 32767 ? 32767 : s);
+  return s >> 7;
 }
 
 constexpr int FAST_THREADS = 256;  // 4 waves per workgroup: WG dispatch rate, not work, bounds tiny WGs
@@ -509,6 +512,200 @@ __device__ __forceinline__ int xcd_order(int b, int s0, int s1) {
   return prefix + ((b - first_x) >> 3);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register path: 8-bit samples, unscaled references.  No LDS and no cross-lane traffic at all: a
+// lane owns FOUR adjacent output columns (one destination dword per row) of an 8-row STRIP of its
+// task; a task of width W occupies W/4 neighbouring lanes per strip and HMAX/8 strips.
+//  load    15 window rows (y0-3 .. y0+11, row index clamped to the plane = border emulation) of 12
+//          bytes from column x0-4+4j: one global_load_dwordx3 each, all in flight together.  Lanes
+//          whose 12 bytes would leave the plane take three dword loads from clamped columns and
+//          replicate the edge sample with v_perm_b32 instead (wave-uniform branch).
+//  rows    per window row: 4 outputs from the 3 dwords with v_alignbyte_b32 + 2 x v_dot4_i32_i8
+//          (samples biased by -128), clipped and re-packed into one dword -> 16 dwords hr[]
+//  4x4     transposes of hr[] with v_perm_b32 give, per column, the intermediate rows packed four
+//          to a dword — the shape the row pass consumed — so the column pass is the same code
+//  cols    4 columns x 8 rows, re-packed by row, one dword store per row (16 lanes = 64 bytes)
+// ≈ 0.35 instructions per output sample against ≈ 1.7 for an LDS-staged 16x16 tile per wave.
+struct RefPlane {
+  const unsigned char *p;
+  int stride, w, h, pad;
+};
+struct RefTable {
+  RefPlane d[VP9HIP_MAX_REFS][3];
+};
+
+template <int W>
+struct RegCfg {
+  static constexpr int L = W / 4;                                                 // lanes per strip
+  static constexpr int HMAX = W == 4 ? 8 : (W == 8 ? 16 : (W == 16 ? 32 : 64));
+  static constexpr int SPT = HMAX / 8;                                            // strips per task
+};
+constexpr int REG_THREADS = 256;
+
+__device__ __forceinline__ unsigned pack4(unsigned o0, unsigned o1, unsigned o2, unsigned o3) {
+  return o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+}
+// outputs i = 0..3 from bytes i+S .. i+S+7 of the twelve (biased) bytes {d0, d1, d2}
+template <int S>
+__device__ __forceinline__ unsigned filt4(unsigned d0, unsigned d1, unsigned d2, unsigned flo, unsigned fhi) {
+  unsigned o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int sh = i + S;  // 0..4
+    const unsigned lo = sh == 0 ? d0 : (sh == 4 ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sh & 3));
+    const unsigned hi = sh == 0 ? d1 : (sh == 4 ? d2 : __builtin_amdgcn_alignbyte(d2, d1, sh & 3));
+    o[i] = dot8(lo, hi, flo, fhi);
+  }
+  return pack4(o[0], o[1], o[2], o[3]);
+}
+// rows a, b, c, e (four samples each) -> columns c0..c3 (samples of rows a, b, c, e)
+__device__ __forceinline__ void transpose4(unsigned a, unsigned b, unsigned c, unsigned e, unsigned &c0, unsigned &c1,
+                                           unsigned &c2, unsigned &c3) {
+  const unsigned t0 = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
+  const unsigned t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+  const unsigned u0 = __builtin_amdgcn_perm(e, c, 0x05010400u);
+  const unsigned u1 = __builtin_amdgcn_perm(e, c, 0x07030602u);
+  c0 = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+  c1 = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+  c2 = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+  c3 = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+}
+// byte k of the result = byte clamp(k + s, 0, 3) of the source dword, s in -3..3
+__device__ const unsigned kEdgeSel[7] = { 0x00000000u, 0x01000000u, 0x02010000u, 0x03020100u,
+                                          0x03030201u, 0x03030302u, 0x03030303u };
+
+template <int W>
+__device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *__restrict__ tasks, int n_tasks,
+                                               const RefTable &refs, const FrameDev &dstf,
+                                               const unsigned *__restrict__ taps) {
+  typedef RegCfg<W> C;
+  const int gl = wg * REG_THREADS + threadIdx.x;
+  const int strip = gl / C::L, j = gl % C::L;
+  const int ti = strip / C::SPT, sub = strip % C::SPT;
+  bool active = ti < n_tasks;
+  vp9hip_inter_task t;
+  if (active) t = tasks[ti];
+  active = active && sub * 8 < t.h;
+  const int plane = active ? t.plane : 0;
+  const int filt = active ? (t.flags >> 1) & 7 : 0;
+  const int nref = active ? ((t.flags & 1) ? 2 : 1) : 0;
+  const int dx = active ? t.dst_x + 4 * j : 0, dy = active ? t.dst_y + sub * 8 : 0;
+  const int dstride = dstf.stride[plane];
+  // awidth is a multiple of 8 and dx of 4: a lane's four columns are visible together or not at all
+  const int vis_h = (active && dx < dstf.awidth[plane]) ? min(min(8, (int)t.h - sub * 8), dstf.aheight[plane] - dy) : 0;
+  unsigned char *dst = (unsigned char *)dstf.plane[plane] + (size_t)dy * dstride + dx;
+  unsigned k[8];  // first prediction of a compound strip
+#pragma unroll
+  for (int y = 0; y < 8; ++y) k[y] = 0;
+
+#pragma unroll 1
+  for (int r = 0; r < 2; ++r) {
+    const bool on = r < nref && vis_h > 0;
+    if (__builtin_amdgcn_ballot_w64(on) == 0) break;
+    if (on) {
+      const int px = r ? t.pos_x[1] : t.pos_x[0], py = r ? t.pos_y[1] : t.pos_y[0];
+      const int x0 = (px >> 4) + 4 * j, y0 = (py >> 4) + sub * 8;
+      const int subx = px & 15, suby = py & 15;
+      const RefPlane rp = refs.d[r ? t.ref[1] : t.ref[0]][plane];
+      const int xs = x0 - 4;
+      unsigned d[15][3];
+      const bool col_ok = xs >= 0 && xs + 12 <= rp.w;
+      if (__builtin_amdgcn_ballot_w64(!col_ok) == 0) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+          const int sy = min(max(y0 - 3 + i, 0), rp.h - 1);
+          __builtin_memcpy(d[i], rp.p + (size_t)sy * rp.stride + xs, 12);
+        }
+      } else {
+        int xc[3];
+        unsigned sel[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int xq = xs + 4 * q;
+          xc[q] = min(max(xq, 0), rp.w - 4);
+          sel[q] = kEdgeSel[min(max(xq - xc[q], -3), 3) + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+          const int sy = min(max(y0 - 3 + i, 0), rp.h - 1);
+          const unsigned char *rowp = rp.p + (size_t)sy * rp.stride;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            unsigned v;
+            __builtin_memcpy(&v, rowp + xc[q], 4);
+            d[i][q] = __builtin_amdgcn_perm(v, v, sel[q]);
+          }
+        }
+      }
+      // rows
+      unsigned hr[16];
+      {
+        const unsigned flo = taps[(filt * 16 + subx) * 2], fhi = taps[(filt * 16 + subx) * 2 + 1];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+          const unsigned f = filt4<1>(d[i][0] ^ 0x80808080u, d[i][1] ^ 0x80808080u, d[i][2] ^ 0x80808080u, flo, fhi);
+          hr[i] = subx == 0 ? d[i][1] : f;
+        }
+        hr[15] = 0;
+      }
+      // columns
+      unsigned col[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        transpose4(hr[4 * g], hr[4 * g + 1], hr[4 * g + 2], hr[4 * g + 3], col[0][g], col[1][g], col[2][g], col[3][g]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) col[c][g] ^= 0x80808080u;
+      }
+      const unsigned flo = taps[(filt * 16 + suby) * 2], fhi = taps[(filt * 16 + suby) * 2 + 1];
+      unsigned out[8];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        unsigned v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = filt4<0>(col[c][m], col[c][m + 1], col[c][m + 2], flo, fhi);
+        // v[c] = column c, rows 4m..4m+3 -> back to rows
+        transpose4(v[0], v[1], v[2], v[3], out[4 * m], out[4 * m + 1], out[4 * m + 2], out[4 * m + 3]);
+      }
+#pragma unroll
+      for (int y = 0; y < 8; ++y) {
+        const unsigned o = suby == 0 ? hr[y + 3] : out[y];
+        // second reference of a compound strip: per byte (a + b + 1) >> 1 (vpx_convolve_avg_c)
+        const unsigned res = r == 1 ? (k[y] | o) - (((k[y] ^ o) >> 1) & 0x7f7f7f7fu) : o;
+        const bool first = nref == 2 && r == 0;
+        k[y] = o;
+        if (!first && y < vis_h) *(unsigned *)(dst + (size_t)y * dstride) = res;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(REG_THREADS) void inter_reg_kernel(const vp9hip_inter_task *__restrict__ tasks,
+                                                                FastPlan plan, RefTable refs, FrameDev dstf,
+                                                                const unsigned *__restrict__ taps) {
+  const int b = blockIdx.x;
+  if (b < plan.wg_start[1])
+    inter_reg_body<4>(xcd_order(b, plan.wg_start[0], plan.wg_start[1]), tasks + plan.task_start[0], plan.task_count[0],
+                      refs, dstf, taps);
+  else if (b < plan.wg_start[2])
+    inter_reg_body<8>(xcd_order(b, plan.wg_start[1], plan.wg_start[2]), tasks + plan.task_start[1], plan.task_count[1],
+                      refs, dstf, taps);
+  else if (b < plan.wg_start[3])
+    inter_reg_body<16>(xcd_order(b, plan.wg_start[2], plan.wg_start[3]), tasks + plan.task_start[2],
+                       plan.task_count[2], refs, dstf, taps);
+  else if (b < plan.wg_start[4])
+    inter_reg_body<32>(xcd_order(b, plan.wg_start[3], plan.wg_start[4]), tasks + plan.task_start[3],
+                       plan.task_count[3], refs, dstf, taps);
+  else
+    inter_reg_body<64>(xcd_order(b, plan.wg_start[4], plan.wg_start[5]), tasks + plan.task_start[4],
+                       plan.task_count[4], refs, dstf, taps);
+}
+
+template <int W>
+int reg_wgs(int n) {
+  constexpr int per_wg = REG_THREADS / RegCfg<W>::L;  // strips per workgroup
+  return (int)(((long long)n * RegCfg<W>::SPT + per_wg - 1) / per_wg);
+}
+
 __global__ __launch_bounds__(FAST_THREADS) void inter_fast_kernel(const vp9hip_inter_task *__restrict__ tasks,
                                                                   FastPlan plan, RefSet refs, FrameDev dstf,
                                                                   const unsigned *__restrict__ taps) {
@@ -612,11 +809,33 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
       acc_t += class_count[k];
     }
     plan.wg_start[5] = acc_w;
-    if (dst->hbd)
+    static const bool use_lds = getenv("VP9HIP_INTER_LDS") != nullptr;
+    if (dst->hbd) {
       hipLaunchKernelGGL(inter_fast16_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d);
-    else
+    } else if (use_lds) {
       hipLaunchKernelGGL(inter_fast_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d,
                          (const unsigned *)ctx->d_taps);
+    } else {
+      RefTable rt;
+      memset(&rt, 0, sizeof(rt));
+      for (int i = 0; i < n_refs; ++i)
+        for (int pl = 0; pl < 3; ++pl) {
+          rt.d[i][pl].p = (const unsigned char *)refs[i].plane[pl];
+          rt.d[i][pl].stride = refs[i].stride[pl];
+          rt.d[i][pl].w = refs[i].width[pl];
+          rt.d[i][pl].h = refs[i].height[pl];
+        }
+      const int rw[5] = { reg_wgs<4>(class_count[0]), reg_wgs<8>(class_count[1]), reg_wgs<16>(class_count[2]),
+                          reg_wgs<32>(class_count[3]), reg_wgs<64>(class_count[4]) };
+      acc_w = 0;
+      for (int k = 0; k < 5; ++k) {
+        plan.wg_start[k] = acc_w;
+        acc_w += rw[k];
+      }
+      plan.wg_start[5] = acc_w;
+      hipLaunchKernelGGL(inter_reg_kernel, dim3(acc_w), dim3(REG_THREADS), 0, ctx->stream, d_tasks, plan, rt, d,
+                         (const unsigned *)ctx->d_taps);
+    }
     VP9HIP_CHECK(ctx, hipGetLastError());
   }
   const int n_gen = class_count[5];
