@@ -439,7 +439,9 @@ class Context:
 
 def sort_inter_tasks(tasks, hbd):
     """Group inter tasks into the six classes vp9hip_inter_pred_batch takes."""
-    unscaled = (tasks["step_x"] == 16).all(axis=1) & (tasks["step_y"] == 16).all(axis=1)
+    compound = (tasks["flags"] & 1).astype(bool)
+    unscaled = (tasks["step_x"][:, 0] == 16) & (tasks["step_y"][:, 0] == 16) & \
+               (~compound | ((tasks["step_x"][:, 1] == 16) & (tasks["step_y"][:, 1] == 16)))  # the second reference only counts when used
     cls = np.full(len(tasks), 5, np.int32)
     # fast classes (8-bit and 16-bit samples) cover the VP9 block shapes: width W with height <= HMAX(W),
     # a multiple of 4

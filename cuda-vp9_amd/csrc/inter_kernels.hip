@@ -12,6 +12,7 @@
 // Algorithmic bytes per task: w*h*bps read (reference) + w*h*bps written (+ w*h*bps more
 // reference for compound) + 32 (descriptor).
 #include "vp9hip_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -120,198 +121,13 @@ __global__ __launch_bounds__(64) void inter_pred_kernel(const vp9hip_inter_task 
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Fast path: 8-bit samples, unscaled references (step 16).  Tasks are grouped by width class on
-// the host (W = 4, 8, 16, 32, 64); a task occupies a SLOT of SL lanes, 64/SL tasks per wave.
-//
-//  stage   (h+7) x (W+8) window -> LDS, 8/16-byte chunks (clamped byte path at frame edges);
-//          window column 0 is source column x0-4 so that output dword j needs window dwords
-//          j, j+1, j+2
-//  rows    lane = (window row, output dword): 4 outputs from 3 dwords with v_alignbyte_b32 +
-//          2 x v_dot4_i32_i8 each (samples biased by -128 to fit i8: sum += 128*128), clipped,
-//          written TRANSPOSED to LDS (T[column][row]) so that the column pass has the same shape
-//  cols    lane = (column, output row dword): 3 dwords of T, same alignbyte/dot4 form, result
-//          clipped and stored (or averaged into dst for the second reference of a compound block)
-// Phase 0 kernels ({0,0,0,128,0,0,0,0}) do not fit i8 and are the identity: handled as copies.
-template <int W>
-struct FastCfg {
-  // A task of width class W is cut into tiles of TW x <=16 outputs; one tile per SLOT of SL lanes.
-  static constexpr int TW = W >= 16 ? 16 : W;                    // tile width
-  static constexpr int HMAX = W == 4 ? 8 : (W == 8 ? 16 : (W == 16 ? 32 : 64));
-  static constexpr int TPT = (W / TW) * (HMAX / 16 ? HMAX / 16 : 1);  // tiles per task (max)
-  static constexpr int SL = TW == 16 ? 64 : (TW == 8 ? 32 : 16);  // lanes per tile
-  static constexpr int G = 64 / SL;                               // tiles per wave
-  static constexpr int DC = TW / 4;                               // output dwords per row
-  static constexpr int CH = TW == 16 ? 16 : 8;                    // staging chunk bytes
-  static constexpr int NCH = (TW + 12 + CH - 1) / CH;             // chunks per window row
-  static constexpr int PW = NCH * CH;                             // window pitch (bytes)
-  static constexpr int PT = 28;                                   // transposed pitch (bytes): 23 rows + pad
-  static constexpr int WIN_BYTES = 23 * PW;
-  static constexpr int T_BYTES = TW * PT;
-  static constexpr int SLOT_BYTES = (WIN_BYTES + T_BYTES + 15) & ~15;
-};
-
-__device__ __forceinline__ int dot8(unsigned lo, unsigned hi, unsigned flo, unsigned fhi) {
-  // 16384 = 128 * sum(taps) undoes the -128 bias of the samples; 64 = rounding
-  int s = __builtin_amdgcn_sdot4((int)lo, (int)flo, 16384 + 64, false);
-  s = __builtin_amdgcn_sdot4((int)hi, (int)fhi, s, false);
-  // clip_pixel(s >> 7), with the clamp BEFORE the shift: clamp-after-shift of two results that are then
-  // packed gets selected as v_ashr_pk_u8_i32, whose destination's upper half did not come out zero on
-  // the MI355X under test (the packed dwords of the register path had garbage in bytes 2-3)
-  s = s < 0 ? 0 : (s > 32767 ? 32767 : s);
-  return s >> 7;
-}
-
 constexpr int FAST_THREADS = 256;  // 4 waves per workgroup: WG dispatch rate, not work, bounds tiny WGs
-constexpr int FAST_LDS = 7680;  // max over W of (FAST_THREADS / SL) * SLOT_BYTES (W = 4: 16 slots x 480 B)
 
 // A tile's slot (16, 32 or 64 lanes) never straddles a wavefront, and a wave's LDS operations execute
 // in issue order: the stages of a tile only need the compiler pinned and lgkmcnt drained, not a
 // workgroup barrier — with s_barrier the four waves of a workgroup waited for the slowest one six
 // times per tile.
 __device__ __forceinline__ void slot_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local"); }
-
-template <int W>
-__device__ __forceinline__ void inter_fast_body(unsigned char *lds, int wg, const vp9hip_inter_task *__restrict__ tasks,
-                                                int n_tasks, const RefSet &refs, const FrameDev &dstf,
-                                                const unsigned *__restrict__ taps) {
-  typedef FastCfg<W> C;
-  constexpr int TW = C::TW;
-  constexpr int GW = FAST_THREADS / C::SL;  // tiles per workgroup
-  static_assert(GW * C::SLOT_BYTES <= FAST_LDS, "LDS budget");
-  const int g = threadIdx.x / C::SL, sl = threadIdx.x % C::SL;
-  const int wid = wg * GW + g;
-  const int ti = wid / C::TPT, tile = wid - ti * C::TPT;
-  const int tx = tile % (W / TW), ty = tile / (W / TW);
-  bool active = ti < n_tasks;
-  vp9hip_inter_task t;
-  if (active) t = tasks[ti];
-  active = active && ty * 16 < t.h;
-  unsigned char *win = lds + g * C::SLOT_BYTES;
-  unsigned char *T = win + C::WIN_BYTES;
-  const int plane = active ? t.plane : 0;
-  const int h = active ? min(16, (int)t.h - ty * 16) : 0;  // tile height: 4, 8 or 16
-  const int filt = active ? (t.flags >> 1) & 7 : 0;
-  const int nref = active ? ((t.flags & 1) ? 2 : 1) : 0;
-  unsigned char *dplane = (unsigned char *)dstf.plane[plane];
-  const int dstride = dstf.stride[plane];
-  const int dx = active ? t.dst_x + tx * TW : 0, dy = active ? t.dst_y + ty * 16 : 0;
-  const int vis_w = active ? min(TW, dstf.awidth[plane] - dx) : 0;
-  const int vis_h = active ? min(h, dstf.aheight[plane] - dy) : 0;
-  const int rows = h + 7;
-  static_assert(TW * 4 == C::SL, "one column-pass item per lane");
-  unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;  // first prediction of a compound tile
-
-  for (int r = 0; r < 2; ++r) {
-    const bool on = active && r < nref && vis_w > 0 && vis_h > 0;
-    int x0 = 0, y0 = 0, subx = 0, suby = 0;
-    if (on) {
-      const int px = t.pos_x[r] + tx * TW * 16, py = t.pos_y[r] + ty * 16 * 16;
-      x0 = px >> 4;
-      y0 = py >> 4;
-      subx = px & 15;
-      suby = py & 15;
-    }
-    if (on) {
-      const FrameDev &rf = refs.f[t.ref[r]];
-      const unsigned char *src = (const unsigned char *)rf.plane[plane];
-      const int sstride = rf.stride[plane];
-      const int fw = rf.width[plane], fh = rf.height[plane];
-      const bool interior = x0 - 4 >= 0 && x0 + TW + 4 <= fw - 1 && x0 - 4 + C::PW <= sstride && y0 - 3 >= 0 &&
-                            y0 + h + 4 <= fh - 1;
-      if (interior) {
-        const unsigned char *base = src + (size_t)(y0 - 3) * sstride + (x0 - 4);
-        for (int i = sl; i < rows * C::NCH; i += C::SL) {
-          const int rr = i / C::NCH, ch = i - rr * C::NCH;
-          const unsigned char *p = base + (size_t)rr * sstride + ch * C::CH;
-          if constexpr (C::CH == 16) {
-            uint4 v;
-            __builtin_memcpy(&v, p, 16);
-            *(uint4 *)(win + rr * C::PW + ch * 16) = v;
-          } else {
-            uint2 v;
-            __builtin_memcpy(&v, p, 8);
-            *(uint2 *)(win + rr * C::PW + ch * 8) = v;
-          }
-        }
-      } else {
-        for (int i = sl; i < rows * (TW + 12); i += C::SL) {
-          const int rr = i / (TW + 12), cc = i - rr * (TW + 12);
-          int sx = x0 - 4 + cc, sy = y0 - 3 + rr;
-          sx = sx < 0 ? 0 : (sx > fw - 1 ? fw - 1 : sx);
-          sy = sy < 0 ? 0 : (sy > fh - 1 ? fh - 1 : sy);
-          win[rr * C::PW + cc] = src[(size_t)sy * sstride + sx];
-        }
-      }
-    }
-    slot_sync();
-    if (on) {
-      // rows -> T (transposed, clipped)
-      const unsigned flo = taps[(filt * 16 + subx) * 2], fhi = taps[(filt * 16 + subx) * 2 + 1];
-      const unsigned *win32 = (const unsigned *)win;
-      for (int i = sl; i < rows * C::DC; i += C::SL) {
-        const int rr = i / C::DC, j = i - rr * C::DC;
-        const unsigned *wp = win32 + rr * (C::PW / 4) + j;
-        unsigned d0 = wp[0], d1 = wp[1], d2 = wp[2];
-        unsigned o0, o1, o2, o3;
-        if (subx == 0) {
-          o0 = d1 & 0xff; o1 = (d1 >> 8) & 0xff; o2 = (d1 >> 16) & 0xff; o3 = d1 >> 24;
-        } else {
-          d0 ^= 0x80808080u; d1 ^= 0x80808080u; d2 ^= 0x80808080u;
-          o0 = dot8(__builtin_amdgcn_alignbyte(d1, d0, 1), __builtin_amdgcn_alignbyte(d2, d1, 1), flo, fhi);
-          o1 = dot8(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2), flo, fhi);
-          o2 = dot8(__builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 3), flo, fhi);
-          o3 = dot8(d1, d2, flo, fhi);
-        }
-        unsigned char *tp = T + (4 * j) * C::PT + rr;
-        tp[0] = (unsigned char)o0;
-        tp[C::PT] = (unsigned char)o1;
-        tp[2 * C::PT] = (unsigned char)o2;
-        tp[3 * C::PT] = (unsigned char)o3;
-      }
-    }
-    slot_sync();
-    if (on) {
-      // columns -> destination
-      const unsigned flo = taps[(filt * 16 + suby) * 2], fhi = taps[(filt * 16 + suby) * 2 + 1];
-      const unsigned *T32 = (const unsigned *)T;
-      unsigned char *dst = dplane + (size_t)dy * dstride + dx;
-      for (int i = sl; i < TW * (h >> 2); i += C::SL) {
-        const int m = i / TW, c = i - m * TW;
-        const unsigned *tp = T32 + c * (C::PT / 4) + m;
-        unsigned t0 = tp[0], t1 = tp[1], t2 = tp[2];
-        unsigned o0, o1, o2, o3;
-        if (suby == 0) {  // output row i is intermediate row i + 3
-          o0 = t0 >> 24; o1 = t1 & 0xff; o2 = (t1 >> 8) & 0xff; o3 = (t1 >> 16) & 0xff;
-        } else {
-          t0 ^= 0x80808080u; t1 ^= 0x80808080u; t2 ^= 0x80808080u;
-          o0 = dot8(t0, t1, flo, fhi);
-          o1 = dot8(__builtin_amdgcn_alignbyte(t1, t0, 1), __builtin_amdgcn_alignbyte(t2, t1, 1), flo, fhi);
-          o2 = dot8(__builtin_amdgcn_alignbyte(t1, t0, 2), __builtin_amdgcn_alignbyte(t2, t1, 2), flo, fhi);
-          o3 = dot8(__builtin_amdgcn_alignbyte(t1, t0, 3), __builtin_amdgcn_alignbyte(t2, t1, 3), flo, fhi);
-        }
-        if (c < vis_w) {
-          unsigned char *d = dst + (size_t)(4 * m) * dstride + c;
-          const int y = 4 * m;
-          if (nref == 2 && r == 0) {
-            // compound: the first prediction stays in registers (same lane -> same four samples in
-            // both passes) instead of a store + reload through memory
-            k0 = o0; k1 = o1; k2 = o2; k3 = o3;
-          } else {
-            if (r == 1) {  // vpx_convolve_avg_c: ROUND_POWER_OF_TWO(dst + pred, 1)
-              o0 = (k0 + o0 + 1) >> 1; o1 = (k1 + o1 + 1) >> 1; o2 = (k2 + o2 + 1) >> 1; o3 = (k3 + o3 + 1) >> 1;
-            }
-            if (y + 0 < vis_h) d[0] = (unsigned char)o0;
-            if (y + 1 < vis_h) d[dstride] = (unsigned char)o1;
-            if (y + 2 < vis_h) d[2 * dstride] = (unsigned char)o2;
-            if (y + 3 < vis_h) d[3 * dstride] = (unsigned char)o3;
-          }
-        }
-      }
-    }
-    slot_sync();
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Fast path for 16-bit samples (high bitdepth, bd 8/10/12), unscaled references: the same tiling as
@@ -541,22 +357,54 @@ struct RegCfg {
   static constexpr int SPT = HMAX / 8;                                            // strips per task
 };
 constexpr int REG_THREADS = 256;
+#ifndef REG_WAVES
+#define REG_WAVES 3
+#endif
 
 __device__ __forceinline__ unsigned pack4(unsigned o0, unsigned o1, unsigned o2, unsigned o3) {
   return o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
 }
+// Four outputs = 8 x v_dot4_i32_i8 + 2 x v_ashr_pk_u8_i32, as one hand-scheduled block:
+//  * the accumulator seed (128 * sum(taps) + 64: un-bias + rounding) comes from an SGPR in the VOP3P
+//    form; the builtin selects the VOP2 v_dot4c form, which needs a v_mov of the seed per output;
+//  * v_ashr_pk_u8_i32 (new in gfx950) shifts, saturates to u8 and packs two results into ONE half of
+//    the destination and preserves the other half (tools/ashr_pk_probe.hip): low half, then op_sel
+//    high half = four clipped samples in two instructions.  (hipcc 7.2 selects the instruction for a
+//    clamp-shift-pack of two values by itself but then treats the untouched half as zero — wrong.)
+//  * the compiler cannot see into the block, so the gfx90a+ hazard "a dot result read by a different
+//    VALU opcode needs 3 wait states" (and "overwritten by one: 4") is met by the order + s_nop 1.
+// Inputs come from ordinary VALU instructions and the packed result is written by a non-dot.
+__device__ __forceinline__ unsigned dot8x4_clip(unsigned lo0, unsigned lo1, unsigned lo2, unsigned lo3, unsigned hi0,
+                                                unsigned hi1, unsigned hi2, unsigned hi3, unsigned flo, unsigned fhi) {
+  unsigned r;
+  int s0, s1, s2, s3;
+  const int seed = 16384 + 64;
+  asm("v_dot4_i32_i8 %1, %5, %13, %15\n\t"
+      "v_dot4_i32_i8 %2, %6, %13, %15\n\t"
+      "v_dot4_i32_i8 %3, %7, %13, %15\n\t"
+      "v_dot4_i32_i8 %4, %8, %13, %15\n\t"
+      "v_dot4_i32_i8 %1, %9, %14, %1\n\t"
+      "v_dot4_i32_i8 %2, %10, %14, %2\n\t"
+      "v_dot4_i32_i8 %3, %11, %14, %3\n\t"
+      "v_dot4_i32_i8 %4, %12, %14, %4\n\t"
+      "s_nop 1\n\t"
+      "v_ashr_pk_u8_i32 %0, %1, %2, 7\n\t"
+      "v_ashr_pk_u8_i32 %0, %3, %4, 7 op_sel:[0,0,0,1]"
+      : "=&v"(r), "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+      : "v"(lo0), "v"(lo1), "v"(lo2), "v"(lo3), "v"(hi0), "v"(hi1), "v"(hi2), "v"(hi3), "v"(flo), "v"(fhi), "s"(seed));
+  return r;
+}
 // outputs i = 0..3 from bytes i+S .. i+S+7 of the twelve (biased) bytes {d0, d1, d2}
 template <int S>
 __device__ __forceinline__ unsigned filt4(unsigned d0, unsigned d1, unsigned d2, unsigned flo, unsigned fhi) {
-  unsigned o[4];
+  unsigned lo[4], hi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int sh = i + S;  // 0..4
-    const unsigned lo = sh == 0 ? d0 : (sh == 4 ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sh & 3));
-    const unsigned hi = sh == 0 ? d1 : (sh == 4 ? d2 : __builtin_amdgcn_alignbyte(d2, d1, sh & 3));
-    o[i] = dot8(lo, hi, flo, fhi);
+    lo[i] = sh == 0 ? d0 : (sh == 4 ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sh & 3));
+    hi[i] = sh == 0 ? d1 : (sh == 4 ? d2 : __builtin_amdgcn_alignbyte(d2, d1, sh & 3));
   }
-  return pack4(o[0], o[1], o[2], o[3]);
+  return dot8x4_clip(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3], flo, fhi);
 }
 // rows a, b, c, e (four samples each) -> columns c0..c3 (samples of rows a, b, c, e)
 __device__ __forceinline__ void transpose4(unsigned a, unsigned b, unsigned c, unsigned e, unsigned &c0, unsigned &c1,
@@ -679,7 +527,7 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
   }
 }
 
-__global__ __launch_bounds__(REG_THREADS) void inter_reg_kernel(const vp9hip_inter_task *__restrict__ tasks,
+__global__ __launch_bounds__(REG_THREADS) __attribute__((amdgpu_waves_per_eu(REG_WAVES, REG_WAVES))) void inter_reg_kernel(const vp9hip_inter_task *__restrict__ tasks,
                                                                 FastPlan plan, RefTable refs, FrameDev dstf,
                                                                 const unsigned *__restrict__ taps) {
   const int b = blockIdx.x;
@@ -706,28 +554,6 @@ int reg_wgs(int n) {
   return (int)(((long long)n * RegCfg<W>::SPT + per_wg - 1) / per_wg);
 }
 
-__global__ __launch_bounds__(FAST_THREADS) void inter_fast_kernel(const vp9hip_inter_task *__restrict__ tasks,
-                                                                  FastPlan plan, RefSet refs, FrameDev dstf,
-                                                                  const unsigned *__restrict__ taps) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[FAST_LDS];
-  const int b = blockIdx.x;
-  if (b < plan.wg_start[1])
-    inter_fast_body<4>(lds, xcd_order(b, plan.wg_start[0], plan.wg_start[1]), tasks + plan.task_start[0],
-                       plan.task_count[0], refs, dstf, taps);
-  else if (b < plan.wg_start[2])
-    inter_fast_body<8>(lds, xcd_order(b, plan.wg_start[1], plan.wg_start[2]), tasks + plan.task_start[1],
-                       plan.task_count[1], refs, dstf, taps);
-  else if (b < plan.wg_start[3])
-    inter_fast_body<16>(lds, xcd_order(b, plan.wg_start[2], plan.wg_start[3]), tasks + plan.task_start[2],
-                        plan.task_count[2], refs, dstf, taps);
-  else if (b < plan.wg_start[4])
-    inter_fast_body<32>(lds, xcd_order(b, plan.wg_start[3], plan.wg_start[4]), tasks + plan.task_start[3],
-                        plan.task_count[3], refs, dstf, taps);
-  else
-    inter_fast_body<64>(lds, xcd_order(b, plan.wg_start[4], plan.wg_start[5]), tasks + plan.task_start[4],
-                        plan.task_count[4], refs, dstf, taps);
-}
-
 __global__ __launch_bounds__(FAST_THREADS) void inter_fast16_kernel(const vp9hip_inter_task *__restrict__ tasks,
                                                                     FastPlan plan, RefSet refs, FrameDev dstf) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[FAST16_LDS];
@@ -751,8 +577,8 @@ __global__ __launch_bounds__(FAST_THREADS) void inter_fast16_kernel(const vp9hip
 
 template <int W>
 int fast_wgs(int n) {
-  constexpr int GW = FAST_THREADS / FastCfg<W>::SL;
-  return (n * FastCfg<W>::TPT + GW - 1) / GW;
+  constexpr int GW = FAST_THREADS / Fast16Cfg<W>::SL;
+  return (n * Fast16Cfg<W>::TPT + GW - 1) / GW;
 }
 
 int upload_taps(vp9hip_ctx *ctx) {
@@ -796,10 +622,22 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
   int rc;
   if (fast_total && !dst->hbd && (rc = upload_taps(ctx))) return rc;
   const vp9hip_inter_task *p = d_tasks + fast_total;
-  if (fast_total) {
+  // the register path replicates edge samples from whole dwords: a reference plane narrower than one
+  // dword (frames under 8 samples wide) sends every task through the generic kernel instead
+  bool tiny_ref = false;
+  for (int i = 0; i < n_refs; ++i)
+    for (int pl = 0; pl < 3; ++pl)
+      if (refs[i].plane[pl] && refs[i].width[pl] < 4) tiny_ref = true;
+  if (fast_total && !dst->hbd && tiny_ref) {
+    hipLaunchKernelGGL(inter_pred_kernel<uint8_t>, dim3(fast_total), dim3(64), 0, ctx->stream, d_tasks, fast_total, rs, d);
+    VP9HIP_CHECK(ctx, hipGetLastError());
+  } else if (fast_total) {
     FastPlan plan;
-    const int wgs[5] = { fast_wgs<4>(class_count[0]), fast_wgs<8>(class_count[1]), fast_wgs<16>(class_count[2]),
-                         fast_wgs<32>(class_count[3]), fast_wgs<64>(class_count[4]) };
+    const int wgs16[5] = { fast_wgs<4>(class_count[0]), fast_wgs<8>(class_count[1]), fast_wgs<16>(class_count[2]),
+                           fast_wgs<32>(class_count[3]), fast_wgs<64>(class_count[4]) };
+    const int wgs8[5] = { reg_wgs<4>(class_count[0]), reg_wgs<8>(class_count[1]), reg_wgs<16>(class_count[2]),
+                          reg_wgs<32>(class_count[3]), reg_wgs<64>(class_count[4]) };
+    const int *wgs = dst->hbd ? wgs16 : wgs8;
     int acc_w = 0, acc_t = 0;
     for (int k = 0; k < 5; ++k) {
       plan.wg_start[k] = acc_w;
@@ -809,12 +647,8 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
       acc_t += class_count[k];
     }
     plan.wg_start[5] = acc_w;
-    static const bool use_lds = getenv("VP9HIP_INTER_LDS") != nullptr;
     if (dst->hbd) {
       hipLaunchKernelGGL(inter_fast16_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d);
-    } else if (use_lds) {
-      hipLaunchKernelGGL(inter_fast_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d,
-                         (const unsigned *)ctx->d_taps);
     } else {
       RefTable rt;
       memset(&rt, 0, sizeof(rt));
@@ -825,14 +659,6 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
           rt.d[i][pl].w = refs[i].width[pl];
           rt.d[i][pl].h = refs[i].height[pl];
         }
-      const int rw[5] = { reg_wgs<4>(class_count[0]), reg_wgs<8>(class_count[1]), reg_wgs<16>(class_count[2]),
-                          reg_wgs<32>(class_count[3]), reg_wgs<64>(class_count[4]) };
-      acc_w = 0;
-      for (int k = 0; k < 5; ++k) {
-        plan.wg_start[k] = acc_w;
-        acc_w += rw[k];
-      }
-      plan.wg_start[5] = acc_w;
       hipLaunchKernelGGL(inter_reg_kernel, dim3(acc_w), dim3(REG_THREADS), 0, ctx->stream, d_tasks, plan, rt, d,
                          (const unsigned *)ctx->d_taps);
     }

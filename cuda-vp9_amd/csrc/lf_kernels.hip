@@ -285,7 +285,7 @@ __device__ __forceinline__ void lf_sb_body(Pix *tile, unsigned *ctl, const vp9hi
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int PPD = 4 / sizeof(Pix);  // samples per dword
   const int lane = threadIdx.x;
-  const int sh = f.bit_depth - 8;
+  const int sh = sizeof(Pix) == 1 ? 0 : f.bit_depth - 8;  // 8-bit samples: a constant, so the clamps fold to v_med3
   constexpr int n = N;         // samples per superblock side in this plane
   constexpr int ncol = N / 8;  // mask columns per mask row
   const int x0 = sc * n, y0 = sr * n;
@@ -388,7 +388,7 @@ __device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9h
   constexpr int KI = (n * DPR + 63) / 64;      // interior dwords per lane
   constexpr int KA = (8 * DPR + 63) / 64;      // above-row dwords per lane
   const int lane = threadIdx.x;
-  const int sh = f.bit_depth - 8;
+  const int sh = sizeof(Pix) == 1 ? 0 : f.bit_depth - 8;  // 8-bit samples: a constant, so the clamps fold to v_med3
   Pix *plane = (Pix *)f.plane[pl];
   const int stride = f.stride[pl];
   const int pw = f.awidth[pl], ph = f.aheight[pl];
@@ -516,7 +516,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   constexpr int KA = (8 * DPR + 63) / 64;
   constexpr int TILE = 72 * TP;  // samples per tile buffer
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sh = f.bit_depth - 8;
+  const int sh = sizeof(Pix) == 1 ? 0 : f.bit_depth - 8;  // 8-bit samples: a constant, so the clamps fold to v_med3
   Pix *plane = (Pix *)f.plane[pl];
   const int stride = f.stride[pl];
   const int pw = f.awidth[pl], ph = f.aheight[pl];

@@ -1,32 +1,33 @@
-// clock_probe: what shader clock does the GPU run at under (a) one tiny wave, (b) a full chip?
-// shader clock = delta(s_memtime) / delta(s_memrealtime) * 100 MHz.
+// Effective shader clock inside short and long kernels: delta s_memtime / delta s_memrealtime x 100 MHz.
+// Build: hipcc --offload-arch=gfx950 -O2 -o tools/build/clock_probe tools/clock_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-__global__ void probe(unsigned long long *out, int iters) {
-  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  int v = threadIdx.x;
-  for (int i = 0; i < iters; ++i) v = v * 1664525 + 1013904223;
-  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; out[2] = v; }
-}
-__global__ void empty() {}
-int main() {
-  unsigned long long *d, h[3];
-  hipMalloc(&d, 64);
-  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int rep = 0; rep < 3; ++rep) {
-    probe<<<1, 64>>>(d, 20000); hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
-    printf("1 wave, short  : %.0f MHz (%llu cycles)\n", 100.0 * h[0] / h[1], h[0]);
+#include <unistd.h>
+__global__ __launch_bounds__(256) void spin(unsigned *out, long long *t, int iters) {
+  unsigned a = threadIdx.x, b = blockIdx.x + 3;
+  const long long m0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a) : "v"(b));
   }
-  // 1000 back-to-back tiny kernels (like the loop-filter diagonal launches)
-  hipEventRecord(a); for (int i = 0; i < 1000; ++i) probe<<<20, 64>>>(d, 2000); hipEventRecord(b); hipEventSynchronize(b);
-  float ms; hipEventElapsedTime(&ms, a, b); hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
-  printf("1000 tiny launches: %.3f us each, clock in last %.0f MHz\n", ms, 100.0 * h[0] / h[1]);
-  hipEventRecord(a); for (int i = 0; i < 1000; ++i) empty<<<20, 64>>>(); hipEventRecord(b); hipEventSynchronize(b);
-  hipEventElapsedTime(&ms, a, b); printf("1000 empty launches: %.3f us each\n", ms);
-  probe<<<4096, 256>>>(d, 2000000); hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
-  printf("full chip, long: %.0f MHz\n", 100.0 * h[0] / h[1]);
-  probe<<<1, 64>>>(d, 2000000); hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
-  printf("1 wave, long   : %.0f MHz\n", 100.0 * h[0] / h[1]);
+  const long long m1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  out[blockIdx.x * 256 + threadIdx.x] = a;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { t[0] = m1 - m0; t[1] = r1 - r0; }
+}
+int main() {
+  unsigned *o; long long *t, h[2];
+  (void)hipMalloc(&o, 2048 * 256 * 4); (void)hipMalloc(&t, 16);
+  const int iters_list[] = { 20, 200, 2000, 20000 };
+  for (int pass = 0; pass < 2; ++pass)
+    for (int k = 0; k < 4; ++k) {
+      if (pass == 1) usleep(20000);  // idle gap before a single launch
+      const int reps = pass == 0 ? 20 : 1;
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(spin, dim3(2048), dim3(256), 0, 0, o, t, iters_list[k]);
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(h, t, 16, hipMemcpyDeviceToHost);
+      printf("%s iters %6d: %8lld memtime ticks in %7.1f us realtime -> %.0f MHz; %.2f ticks per v_mad (2 waves/SIMD... 8 waves/CU x8 WG)\n",
+             pass == 0 ? "20 back-to-back" : "after 20 ms idle", iters_list[k], h[0], h[1] / 100.0, h[0] / (h[1] / 100.0),
+             (double)h[0] / (iters_list[k] * 64.0));
+    }
   return 0;
 }

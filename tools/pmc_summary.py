@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-FAMILY = (("inter_fast_kernel", "convolve"), ("inter_pred_kernel", "convolve_generic"), ("idct_add", "idct_add"),
+FAMILY = (("inter_fast_kernel", "convolve"), ("inter_fast16_kernel", "convolve"), ("inter_reg_kernel", "convolve"), ("inter_pred_kernel", "convolve_generic"), ("idct_add", "idct_add"),
           ("intra_island_kernel", "intra"), ("intra_wave_kernel", "intra_waves"), ("lf_rows", "loop_filter"),
           ("lf_diag", "loop_filter_diag"), ("residual_", "residual"))
 
