@@ -342,18 +342,27 @@ __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_ta
       intra_chunk<Pix, HBD>(edge, tiles, tasks, isl.task_start + ti, ti < end, coeffs, f);
     }
     __syncthreads();
-  }
-  // Overlap with the loop filter (vp9hip_intra_islands_lf): tell the superblocks this island touches that
-  // it is done.  Every wave's stores are complete (the __syncthreads above drains vmcnt and joins the
-  // waves); one agent-scope release writes this XCD's dirty L2 lines back, then the counters go up —
-  // the producer half of the hand-off recipe of MI355X_MICROARCH.md.
-  if (sb_done != nullptr && threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const int rlo = (int)(isl.reserved & 0xff), rhi = (int)((isl.reserved >> 8) & 0xff);
-    const int clo = (int)((isl.reserved >> 16) & 0xff), chi = (int)(isl.reserved >> 24);
-    for (int r = rlo; r <= rhi; ++r)
-      for (int c = clo; c <= chi; ++c)
-        __hip_atomic_fetch_add(&sb_done[r * sb_cols + c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Overlap with the loop filter (vp9hip_intra_islands_lf): a task with bit 0 of `reserved` set is the
+    // LAST task of this island inside its luma superblock (the packer marks it); once its wave is done,
+    // everything this island does inside that superblock is done, and the superblock's counter goes up —
+    // the loop filter follows the walk superblock by superblock instead of waiting for whole islands
+    // (the deepest one runs for ~60 waves).  Every wave's stores are complete (the __syncthreads above
+    // drains vmcnt and joins the waves); an agent-scope release writes this XCD's dirty L2 lines back
+    // before the counter moves: the producer half of the hand-off recipe of MI355X_MICROARCH.md.
+    // (Write-through stores instead of the fence were measured: they put the memory round trip into
+    // every wave of the chain, 240 -> 384 us for the walk.)
+    if (sb_done != nullptr) {
+      for (int ti = begin + (int)threadIdx.x; ti < end; ti += (int)blockDim.x) {
+        const vp9hip_intra_task tk = tasks[isl.task_start + ti];
+        if (tk.reserved & 1) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          // chroma subsampling from the plane sizes (the overlapped call takes 4:2:0 or single-plane frames)
+          const int sx = tk.plane && f.awidth[tk.plane] < f.awidth[0], sy = tk.plane && f.aheight[tk.plane] < f.aheight[0];
+          const int sb = (((int)tk.y << sy) >> 6) * sb_cols + (((int)tk.x << sx) >> 6);
+          __hip_atomic_fetch_add(&sb_done[sb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
   }
 }
 

@@ -664,9 +664,11 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
     int32_t *k1 = (int32_t *)pk->order_a.p, *k2 = k1 + na + 1;
     vp9hip_intra_task *tmp = (vp9hip_intra_task *)pk->inter.p; /* scratch: the unsorted inter list is dead */
     int n_isl = 0, n_big = 0;
-    if (vec_reserve(&pk->rows_expected, sizeof(int32_t) * ((size_t)sb_rows * sb_cols + 1))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+    /* [0, n_sb]: expected counts; (n_sb, 2 n_sb]: last island seen per superblock (stamp) */
+    if (vec_reserve(&pk->rows_expected, sizeof(int32_t) * 2 * ((size_t)sb_rows * sb_cols + 1))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
     int32_t *rexp = (int32_t *)pk->rows_expected.p;
-    memset(rexp, 0, sizeof(int32_t) * ((size_t)sb_rows * sb_cols + 1));
+    int32_t *sb_stamp = rexp + (size_t)sb_rows * sb_cols + 1;
+    memset(rexp, 0, sizeof(int32_t) * 2 * ((size_t)sb_rows * sb_cols + 1));
     out->island_sb_expected = rexp;
     /* gather, keeping decode order */
     for (int i = 0; i < na; ++i) {
@@ -759,8 +761,24 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
           if (rhi > sb_rows - 1) rhi = sb_rows - 1;
           if (chi > sb_cols - 1) chi = sb_cols - 1;
           r->reserved = (uint32_t)rlo | ((uint32_t)rhi << 8) | ((uint32_t)clo << 16) | ((uint32_t)chi << 24);
-          for (int q = rlo; q <= rhi; ++q)
-            for (int c = clo; c <= chi; ++c) ++rexp[q * sb_cols + c];
+        }
+        /* the LAST task (highest wave, then list order) of the island inside each luma superblock gets
+         * bit 0 of `reserved`: when its wave is done the island is done with that superblock, and the
+         * island kernel says so to the loop filter (vp9hip_intra_islands_lf); island_sb_expected counts the
+         * marks per superblock.  A transform block never straddles superblocks. */
+        for (int k = e - 1; k >= a; --k) {
+          vp9hip_intra_task *t = &isl[k];
+          const int sc = t->plane ? ss : 0;
+          int q = (t->y << sc) >> 6, c2 = (t->x << sc) >> 6;
+          if (q > sb_rows - 1) q = sb_rows - 1;
+          if (c2 > sb_cols - 1) c2 = sb_cols - 1;
+          const int sb = q * sb_cols + c2;
+          t->reserved = 0;
+          if (sb_stamp[sb] != n_is) { /* n_is = 1-based id of this island */
+            sb_stamp[sb] = n_is;
+            t->reserved = 1;
+            ++rexp[sb];
+          }
         }
         a = e;
       }

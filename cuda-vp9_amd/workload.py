@@ -253,14 +253,28 @@ def intra_levels(tasks, dims, want_components=False):
     return lv
 
 
-def island_sb_expected(islands, sb_rows, sb_cols):
-    """expected[r, c] = number of islands whose samples touch luma superblock (r, c)."""
-    exp = np.zeros((sb_rows, sb_cols), np.int32)
-    for r in islands:
-        v = int(r["reserved"])
-        rlo, rhi, clo, chi = v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff, (v >> 24) & 0xff
-        exp[rlo:min(rhi, sb_rows - 1) + 1, clo:min(chi, sb_cols - 1) + 1] += 1
-    return exp.ravel()
+def island_sb_expected(isl_tasks, islands, sb_rows, sb_cols):
+    """Marks, per island, the LAST task (list order = wave order) inside each luma superblock with bit 0 of
+    `reserved` — when its wave is done the island is done with that superblock, which the island kernel
+    reports to the loop filter running beside it — and returns expected[r * sb_cols + c] = number of
+    marks in superblock (r, c) (vp9hip_intra_islands_lf; mirrors vp9hip_pack.c)."""
+    exp = np.zeros(sb_rows * sb_cols, np.int32)
+    isl_tasks["reserved"] = 0
+    wave_ends = None
+    starts = np.sort(islands["task_start"].astype(np.int64)) if len(islands) else np.zeros(0, np.int64)
+    ends = np.r_[starts[1:], len(isl_tasks)]
+    for a, b in zip(starts, ends):
+        t = isl_tasks[a:b]
+        sc = np.where(t["plane"] > 0, 1, 0)
+        sb = np.minimum((t["y"].astype(np.int64) << sc) >> 6, sb_rows - 1) * sb_cols + \
+             np.minimum((t["x"].astype(np.int64) << sc) >> 6, sb_cols - 1)
+        # last occurrence of each superblock in list order
+        rev = sb[::-1]
+        _, first_in_rev = np.unique(rev, return_index=True)
+        last = len(sb) - 1 - first_in_rev
+        isl_tasks["reserved"][a + last] = 1
+        np.add.at(exp, sb[last], 1)
+    return exp
 
 
 def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
@@ -472,6 +486,6 @@ def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_fr
                 intra_decode_order=itasks, intra_sorted=itasks_sorted, wave_start=wave_start, n_waves=n_waves,
                 intra_island_tasks=isl_tasks, intra_islands=islands, intra_island_wave_off=isl_wave_off,
                 intra_big_tasks=big_tasks, intra_big_wave_start=big_wave_start,
-                island_sb_expected=island_sb_expected(islands, sb_rows, sb_cols),
+                island_sb_expected=island_sb_expected(isl_tasks, islands, sb_rows, sb_cols),
                 lfm=lfm, sb_rows=sb_rows, sb_cols=sb_cols, thresholds=lf_thresholds(sharpness),
                 n_blocks=nb, n_txb=nt)

@@ -170,7 +170,7 @@ typedef struct vp9hip_intra_task {
   uint16_t eob;
   uint8_t flags;   /* bit0 have_top, bit1 have_left, bit2 have_right, bit3 raw edges: read all 2*bs
                       above samples from the frame instead of replicating (rtcd twins only) */
-  uint8_t reserved;
+  uint8_t reserved; /* bit0: last task of its island inside its luma superblock (vp9hip_intra_islands_lf) */
 } vp9hip_intra_task; /* 16 bytes */
 
 int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
@@ -226,8 +226,10 @@ int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_ro
 /* The island walk and the loop filter of the same frame side by side (HIP streams inside the context):
  * the filter takes superblock (r, c) once the islands touching superblocks (r..r+1, c-1..c+1) are done
  * (an unfinished island there would still read samples the filter changes), not when the whole walk
- * is.  d_sb_expected (DEVICE, sb_rows * sb_cols entries) = number of islands per superblock,
- * islands[i].reserved = the superblocks an island touches (vp9hip_pack.h fills both).  Frames with
+ * is.  The hand-over is per (island, superblock): bit 0 of vp9hip_intra_task.reserved marks the LAST
+ * task of its island inside a luma superblock (list order = wave order), and d_sb_expected (DEVICE,
+ * sb_rows * sb_cols entries) = number of marked tasks per superblock (vp9hip_pack.h fills both;
+ * islands[i].reserved = the superblock bounding box of an island is informational).  Frames with
  * very large components (key frames: the vp9hip_intra_pred_waves remainder) use the two calls in
  * sequence instead.  Ordered after everything enqueued before on the context, and later work is
  * ordered after both kernels.  At most 255 x 255 superblocks. */

@@ -239,6 +239,44 @@ def test_island_and_wave_lists_preserve_dependencies(hip, oracle, W, H, kw, seed
     pk.close()
 
 
+@pytest.mark.parametrize("W,H,kw,seed", [(352, 288, dict(intra_frac=0.3), 5), (640, 360, dict(intra_frac=0.08), 6),
+                                          (200, 136, dict(intra_frac=0.5), 7)])
+def test_island_superblock_marks(hip, W, H, kw, seed):
+    """vp9hip_intra_islands_lf hand-over data: per island exactly the LAST task (list order) inside each luma
+    superblock carries bit 0 of `reserved`, island_sb_expected counts the marks per superblock, and the
+    Python mirror used by bench.py (workload.island_sb_expected) produces the same marks and counts."""
+    import importlib
+    workload = importlib.import_module(hip.__name__ + ".workload")
+    rng = np.random.default_rng(seed)
+    blocks = blockgen.gen_blocks(rng, W, H, hip.BLOCK_DTYPE, **kw)
+    pk = hip.Packer()
+    L = pk.pack(_params(hip, W, H, 8, lf=1), blocks)
+    isl, woff, tasks, exp = L["intra_islands"], L["intra_island_wave_off"], L["intra_island_tasks"], L["island_sb_expected"]
+    sb_rows, sb_cols = L["sb_rows"], L["sb_cols"]
+    assert len(isl) > 0 and len(exp) == sb_rows * sb_cols
+    count = np.zeros(sb_rows * sb_cols, np.int64)
+    for r in isl:
+        n = int(woff[r["wave_off_start"] + r["n_waves"]])
+        t = tasks[r["task_start"]:r["task_start"] + n]
+        sc = (t["plane"] > 0).astype(np.int64)
+        sb = ((t["y"].astype(np.int64) << sc) >> 6) * sb_cols + ((t["x"].astype(np.int64) << sc) >> 6)
+        assert sb.max() < sb_rows * sb_cols
+        last = {int(v): i for i, v in enumerate(sb)}  # last index per superblock
+        want = np.zeros(n, np.uint8)
+        want[list(last.values())] = 1
+        assert np.array_equal(t["reserved"] & 1, want)
+        # a marked task must be in the island's last wave that touches its superblock
+        wave_of = np.searchsorted(woff[r["wave_off_start"]:r["wave_off_start"] + r["n_waves"] + 1], np.arange(n), side="right") - 1
+        for v, i in last.items():
+            assert wave_of[i] == wave_of[sb == v].max()
+            count[v] += 1
+    assert np.array_equal(count, exp)
+    mine = tasks.copy()
+    assert np.array_equal(workload.island_sb_expected(mine, isl, sb_rows, sb_cols), exp)
+    assert np.array_equal(mine["reserved"], tasks["reserved"])
+    pk.close()
+
+
 def test_packer_rejects_bad_input(hip):
     pk = hip.Packer()
     blocks = np.zeros(1, hip.BLOCK_DTYPE)
