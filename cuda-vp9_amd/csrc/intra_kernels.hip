@@ -14,6 +14,7 @@
 // coefficients when coded).
 #include "txfm_device.h"
 #include "vp9hip_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -171,6 +172,38 @@ __device__ __forceinline__ void col_pass(const int *tile, int t, int tx_type, bo
   for (int k = 0; k < N; ++k) v[k] = txfm::add32(v[k], 1 << (shift - 1)) >> shift;
 }
 
+// Residual column t (rows 0..N-1) of a coded block: DC-only forms, a residual handed in directly, or the
+// column pass over the row-pass output in `tile`.
+template <int N, bool HBD>
+__device__ __forceinline__ void block_residual(const vp9hip_intra_task &tk, int t, const int *tile, int dc_coeff,
+                                               int dc_kind, int *v) {
+  if (dc_kind == 1) {  // vpx_idctNxN_1_add_c
+    const int a1 = txfm::dc_only<N, HBD>(dc_coeff);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = a1;
+  } else if (dc_kind == 2) {  // vpx_iwht4x4_1_add_c
+    txfm::i64 a1 = dc_coeff >> 2, e1 = a1 >> 1;
+    a1 -= e1;
+    const int ip = t == 0 ? (int)a1 : (int)e1;
+    const int e = ip >> 1;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = e;
+    v[0] = ip - e;
+  } else if (tk.tx_type & 0x40) {  // residual given directly (residual-plane mode), raster NxN
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = tile[k * TPITCH + t];
+  } else {
+    col_pass<N, HBD>(tile, t, tk.tx_type & 3, tk.tx_type & 0x80, v);
+  }
+}
+
+// Where intra_residual_kernel leaves the residual of every coded island task and the island walk
+// picks it up: one int32 per sample at the sample's position, planes back to back (context scratch).
+struct ResidDev {
+  int *p;
+  int off[3], stride[3];
+};
+
 template <int N, typename Pix, bool HBD>
 __device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t, const int *E, const int *tile,
                                              bool coded, int dc_coeff, int dc_kind, const FrameDev &f) {
@@ -179,24 +212,30 @@ __device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t,
   predict_column<N>(tk.mode, t, E, tk.flags & 1, (tk.flags >> 1) & 1, f.bit_depth, p);
   if (coded) {
     int v[N];
-    if (dc_kind == 1) {  // vpx_idctNxN_1_add_c
-      const int a1 = txfm::dc_only<N, HBD>(dc_coeff);
+    block_residual<N, HBD>(tk, t, tile, dc_coeff, dc_kind, v);
+    const int maxv = (1 << f.bit_depth) - 1;
 #pragma unroll
-      for (int k = 0; k < N; ++k) v[k] = a1;
-    } else if (dc_kind == 2) {  // vpx_iwht4x4_1_add_c
-      txfm::i64 a1 = dc_coeff >> 2, e1 = a1 >> 1;
-      a1 -= e1;
-      const int ip = t == 0 ? (int)a1 : (int)e1;
-      const int e = ip >> 1;
+    for (int k = 0; k < N; ++k) p[k] = clip_to(txfm::add32(p[k], v[k]), maxv);
+  }
+  const int pl = tk.plane;
+  const int x = tk.x + t;
+  if (x >= f.awidth[pl]) return;
+  Pix *dst = (Pix *)f.plane[pl] + (size_t)tk.y * f.stride[pl] + x;
+  const int rows = min(N, f.aheight[pl] - (int)tk.y);
 #pragma unroll
-      for (int k = 0; k < N; ++k) v[k] = e;
-      v[0] = ip - e;
-    } else if (tk.tx_type & 0x40) {  // residual given directly (residual-plane mode), raster NxN
-#pragma unroll
-      for (int k = 0; k < N; ++k) v[k] = tile[k * TPITCH + t];
-    } else {
-      col_pass<N, HBD>(tile, t, tk.tx_type & 3, tk.tx_type & 0x80, v);
-    }
+  for (int k = 0; k < N; ++k)
+    if (k < rows) dst[(size_t)k * f.stride[pl]] = (Pix)p[k];
+}
+
+// The walk's form: the residual was computed ahead of the walk (it does not depend on the neighbours)
+// and v[] was loaded before the edges were assembled.
+template <int N, typename Pix>
+__device__ __forceinline__ void finish_block_res(const vp9hip_intra_task &tk, int t, const int *E, const int *v,
+                                                 bool coded, const FrameDev &f) {
+  if (t >= N) return;
+  int p[N];
+  predict_column<N>(tk.mode, t, E, tk.flags & 1, (tk.flags >> 1) & 1, f.bit_depth, p);
+  if (coded) {
     const int maxv = (1 << f.bit_depth) - 1;
 #pragma unroll
     for (int k = 0; k < N; ++k) p[k] = clip_to(txfm::add32(p[k], v[k]), maxv);
@@ -310,6 +349,184 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
   }
 }
 
+// ---- residual ahead of the walk ----------------------------------------------------------------
+// The residual of an intra block depends on its coefficients only; the prediction depends on the
+// neighbours.  intra_residual_kernel runs the inverse transforms of every coded island task in
+// parallel (no waves) into ResidDev; the walk (intra_chunk_res) then has only edge assembly +
+// prediction + add on its dependent chain, and its residual loads are issued before the edge loads.
+template <int N, bool HBD>
+__device__ __forceinline__ void residual_block(const vp9hip_intra_task &tk, int t, int *tile, int dc_coeff, int dc_kind,
+                                               const ResidDev &rd, const FrameDev &f) {
+  if (t >= N) return;
+  int v[N];
+  block_residual<N, HBD>(tk, t, tile, dc_coeff, dc_kind, v);
+  const int pl = tk.plane;
+  const int x = tk.x + t;
+  if (x >= f.awidth[pl]) return;
+  int *dst = rd.p + rd.off[pl] + (size_t)tk.y * rd.stride[pl] + x;
+  const int rows = min(N, f.aheight[pl] - (int)tk.y);
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (k < rows) dst[(size_t)k * rd.stride[pl]] = v[k];
+}
+
+template <bool HBD>
+__device__ __forceinline__ void residual_chunk(int (*tiles)[32 * TPITCH], const vp9hip_intra_task *__restrict__ tasks,
+                                               int index, bool active, const int32_t *__restrict__ coeffs,
+                                               const ResidDev &rd, const FrameDev &f) {
+  const int slot = threadIdx.x / SLOT, t = threadIdx.x % SLOT;
+  vp9hip_intra_task tk;
+  memset(&tk, 0, sizeof(tk));
+  if (active) tk = tasks[index];
+  const int bs = 4 << tk.tx_size;
+  const bool lossless = tk.tx_type & 0x80;
+  const bool identity = tk.tx_type & 0x40;
+  const bool coded = active && tk.eob > 0;
+  int *tile = tiles[slot];
+  int dc_kind = 0, dc_coeff = 0;
+  if (coded) {  // same selection of forms as intra_chunk
+    const int32_t *src = coeffs + tk.coeff_off;
+    if (!identity) {
+      if (!lossless && ((tk.tx_type & 3) == 0 || bs == 32) && (bs == 4 ? tk.eob <= 1 : tk.eob == 1)) dc_kind = 1;
+      if (lossless && tk.eob <= 1) dc_kind = 2;
+    }
+    if (dc_kind)
+      dc_coeff = src[0];
+    else if (t < bs)
+      for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = src[i * bs + t];
+  }
+  slot_sync();
+  if (coded && !dc_kind && !identity && t < bs) {
+    const int tt = tk.tx_type & 3;
+    switch (tk.tx_size) {
+      case 0: row_pass<4, HBD>(tile, t, tt, lossless); break;
+      case 1: row_pass<8, HBD>(tile, t, tt, false); break;
+      case 2: row_pass<16, HBD>(tile, t, tt, false); break;
+      default: row_pass<32, HBD>(tile, t, 0, false); break;
+    }
+  }
+  slot_sync();
+  if (coded) {
+    switch (tk.tx_size) {
+      case 0: residual_block<4, HBD>(tk, t, tile, dc_coeff, dc_kind, rd, f); break;
+      case 1: residual_block<8, HBD>(tk, t, tile, dc_coeff, dc_kind, rd, f); break;
+      case 2: residual_block<16, HBD>(tk, t, tile, dc_coeff, dc_kind, rd, f); break;
+      default: residual_block<32, HBD>(tk, t, tile, dc_coeff, dc_kind, rd, f); break;
+    }
+  }
+  slot_sync();  // the tile is reused by the next chunk of this slot
+}
+
+constexpr int RESID_Y = 8;  // workgroups per island: workgroup (i, j) takes chunks j, j + RESID_Y, ... of island i
+template <bool HBD>
+__global__ __launch_bounds__(256) void intra_residual_kernel(const vp9hip_intra_task *__restrict__ tasks,
+                                                             const vp9hip_intra_island *__restrict__ islands,
+                                                             const int32_t *__restrict__ wave_off,
+                                                             const int32_t *__restrict__ coeffs, ResidDev rd, FrameDev f) {
+  __shared__ int tiles[SLOTS][32 * TPITCH];
+  const vp9hip_intra_island isl = islands[blockIdx.x];
+  const int n = wave_off[isl.wave_off_start + isl.n_waves];  // tasks of the island
+  const int slot = threadIdx.x / SLOT;
+  for (int base = blockIdx.y * SLOTS; base < n; base += RESID_Y * SLOTS) {
+    const int ti = base + slot;
+    residual_chunk<HBD>(tiles, tasks, isl.task_start + ti, ti < n, coeffs, rd, f);
+  }
+}
+
+template <typename Pix>
+__device__ __forceinline__ void intra_chunk_res(int (*edge)[ESIZE], const vp9hip_intra_task *__restrict__ tasks, int index,
+                                                bool active, const ResidDev &rd, const FrameDev &f) {
+  const int slot = threadIdx.x / SLOT, t = threadIdx.x % SLOT;
+  vp9hip_intra_task tk;
+  memset(&tk, 0, sizeof(tk));
+  if (active) tk = tasks[index];
+  const int bs = 4 << tk.tx_size;
+  const int pl = tk.plane;
+  const bool coded = active && rd.p != nullptr && tk.eob > 0;
+  int *E = edge[slot] + EOFF;
+  // residual column of this lane: independent of the neighbours, so for the small blocks (the bulk of a
+  // deep chain) the loads go out before the edge loads; 16x16 / 32x32 columns are loaded where they
+  // are used (32 more live registers across the edge assembly would be parked in AGPRs)
+  int v4[4], v8[8];
+  const bool has_col = coded && t < bs && (int)tk.x + t < f.awidth[pl];
+  const int *rp = rd.p + rd.off[pl] + (size_t)tk.y * rd.stride[pl] + tk.x + t;
+  const int rs = rd.stride[pl];
+  const int rrows = min(bs, f.aheight[pl] - (int)tk.y);
+  if (has_col) {
+    if (tk.tx_size == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v4[k] = k < rrows ? rp[(size_t)k * rs] : 0;
+    } else if (tk.tx_size == 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v8[k] = k < rrows ? rp[(size_t)k * rs] : 0;
+    }
+  }
+  if (active) {
+    const Pix *plane = (const Pix *)f.plane[pl];
+    const int stride = f.stride[pl];
+    const int fw = f.awidth[pl], fh = f.aheight[pl];
+    const int base = 128 << (f.bit_depth - 8);
+    const bool have_top = tk.flags & 1, have_left = (tk.flags >> 1) & 1, have_right = (tk.flags >> 2) & 1;
+    const int x = tk.x, y = tk.y;
+    {  // above row (same rules as intra_chunk)
+      int take;
+      const bool ext = (bs == 4 && have_right) || (tk.flags & 8);
+      if (x + 2 * bs <= fw)
+        take = ext ? 2 * bs : bs;
+      else if (x + bs <= fw)
+        take = ext ? fw - x : bs;
+      else
+        take = fw - x;
+      for (int i = t; i < 2 * bs; i += SLOT) {
+        int e;
+        if (have_top)
+          e = plane[(size_t)(y - 1) * stride + x + (i < take ? i : take - 1)];
+        else
+          e = base - 1;
+        E[1 + i] = e;
+      }
+      if (t == 0) E[0] = have_top ? (have_left ? (int)plane[(size_t)(y - 1) * stride + x - 1] : base + 1) : base - 1;
+    }
+    {
+      const int valid = (y + bs <= fh) ? bs : fh - y;
+      for (int i = t; i < bs; i += SLOT) {
+        int e;
+        if (have_left)
+          e = plane[(size_t)(y + (i < valid ? i : valid - 1)) * stride + x - 1];
+        else
+          e = base + 1;
+        E[-1 - i] = e;
+      }
+    }
+  }
+  slot_sync();
+  if (active) {
+    switch (tk.tx_size) {
+      case 0: finish_block_res<4, Pix>(tk, t, E, v4, coded, f); break;
+      case 1: finish_block_res<8, Pix>(tk, t, E, v8, coded, f); break;
+      case 2: {
+        int v16[16];
+        if (has_col) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v16[k] = k < rrows ? rp[(size_t)k * rs] : 0;
+        }
+        finish_block_res<16, Pix>(tk, t, E, v16, coded, f);
+        break;
+      }
+      default: {
+        int v32[32];
+        if (has_col) {
+#pragma unroll
+          for (int k = 0; k < 32; ++k) v32[k] = k < rrows ? rp[(size_t)k * rs] : 0;
+        }
+        finish_block_res<32, Pix>(tk, t, E, v32, coded, f);
+        break;
+      }
+    }
+  }
+  slot_sync();  // E is rewritten by the next chunk of this slot
+}
+
 // One launch per dependency wave of the whole frame (deep structures: key frames).
 template <typename Pix, bool HBD>
 __global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task *__restrict__ tasks, int first,
@@ -325,21 +542,24 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task
 // with a workgroup barrier between waves — no kernel boundary, no inter-workgroup traffic.
 // __syncthreads() orders the global stores of one wave before the edge loads of the next for
 // the threads of this workgroup (same CU, same L1).
-template <typename Pix, bool HBD>
+template <typename Pix, bool HBD, bool RES>
 __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_task *__restrict__ tasks,
                                                            const vp9hip_intra_island *__restrict__ islands,
                                                            const int32_t *__restrict__ wave_off,
-                                                           const int32_t *__restrict__ coeffs, FrameDev f,
+                                                           const int32_t *__restrict__ coeffs, ResidDev rd, FrameDev f,
                                                            int *__restrict__ sb_done, int sb_cols) {
   __shared__ int edge[SLOTS][ESIZE];
-  __shared__ int tiles[SLOTS][32 * TPITCH];
+  __shared__ int tiles[RES ? 1 : SLOTS][RES ? 1 : 32 * TPITCH];
   const vp9hip_intra_island isl = islands[blockIdx.x];
   const int slot = threadIdx.x / SLOT;
   for (int w = 0; w < isl.n_waves; ++w) {
     const int begin = wave_off[isl.wave_off_start + w], end = wave_off[isl.wave_off_start + w + 1];
     for (int base = begin; base < end; base += SLOTS) {
       const int ti = base + slot;
-      intra_chunk<Pix, HBD>(edge, tiles, tasks, isl.task_start + ti, ti < end, coeffs, f);
+      if constexpr (RES)
+        intra_chunk_res<Pix>(edge, tasks, isl.task_start + ti, ti < end, rd, f);
+      else
+        intra_chunk<Pix, HBD>(edge, (int (*)[32 * TPITCH])tiles, tasks, isl.task_start + ti, ti < end, coeffs, f);
     }
     __syncthreads();
     // Overlap with the loop filter (vp9hip_intra_islands_lf): a task with bit 0 of `reserved` set is the
@@ -368,16 +588,63 @@ __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_ta
 
 }  // namespace
 
+// Residual scratch of the context: one int32 per sample of the frame, planes back to back.  Growing it
+// synchronises, so callers that fork streams make sure of it first.
+int vp9hip_ensure_resid(vp9hip_ctx *ctx, const vp9hip_frame *frame) {
+  size_t need = 0;
+  for (int pl = 0; pl < 3; ++pl)
+    if (frame->plane[pl]) need += (size_t)frame->awidth[pl] * frame->aheight[pl] * sizeof(int);
+  if (need <= ctx->resid_bytes) return VP9HIP_OK;
+  if (ctx->resid) VP9HIP_CHECK(ctx, hipFree(ctx->resid));
+  ctx->resid = nullptr;
+  ctx->resid_bytes = 0;
+  VP9HIP_CHECK(ctx, hipMalloc(&ctx->resid, need));
+  ctx->resid_bytes = need;
+  return VP9HIP_OK;
+}
+
 int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
                           const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_sb_done, int sb_cols) {
   const FrameDev f = to_dev(frame);
+  static const bool no_res = getenv("VP9HIP_INTRA_RES") && atoi(getenv("VP9HIP_INTRA_RES")) == 0;
+  ResidDev rd;
+  memset(&rd, 0, sizeof(rd));
+  if (no_res) {
+    if (frame->hbd)
+      hipLaunchKernelGGL((intra_island_kernel<uint16_t, true, false>), dim3(n_islands), dim3(256), 0, st, d_tasks,
+                         d_islands, d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);
+    else
+      hipLaunchKernelGGL((intra_island_kernel<uint8_t, false, false>), dim3(n_islands), dim3(256), 0, st, d_tasks,
+                         d_islands, d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);
+    VP9HIP_CHECK(ctx, hipGetLastError());
+    return VP9HIP_OK;
+  }
+  if (d_coeffs) {
+    // the inverse transforms of every coded task, in parallel, ahead of the dependent walk
+    int rc = vp9hip_ensure_resid(ctx, frame);
+    if (rc) return rc;
+    rd.p = (int *)ctx->resid;
+    int acc = 0;
+    for (int pl = 0; pl < 3; ++pl) {
+      rd.off[pl] = acc;
+      rd.stride[pl] = frame->awidth[pl];
+      if (frame->plane[pl]) acc += frame->awidth[pl] * frame->aheight[pl];
+    }
+    if (frame->hbd)
+      hipLaunchKernelGGL((intra_residual_kernel<true>), dim3(n_islands, RESID_Y), dim3(256), 0, st, d_tasks, d_islands,
+                         d_wave_off, d_coeffs, rd, f);
+    else
+      hipLaunchKernelGGL((intra_residual_kernel<false>), dim3(n_islands, RESID_Y), dim3(256), 0, st, d_tasks, d_islands,
+                         d_wave_off, d_coeffs, rd, f);
+    VP9HIP_CHECK(ctx, hipGetLastError());
+  }
   if (frame->hbd)
-    hipLaunchKernelGGL((intra_island_kernel<uint16_t, true>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, f, d_sb_done, sb_cols);
+    hipLaunchKernelGGL((intra_island_kernel<uint16_t, true, true>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
+                       d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);
   else
-    hipLaunchKernelGGL((intra_island_kernel<uint8_t, false>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, f, d_sb_done, sb_cols);
+    hipLaunchKernelGGL((intra_island_kernel<uint8_t, false, true>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
+                       d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);
   VP9HIP_CHECK(ctx, hipGetLastError());
   return VP9HIP_OK;
 }

@@ -848,6 +848,10 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
     int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
     if (rc) return rc;
   }
+  if (d_coeffs) {
+    int rc = vp9hip_ensure_resid(ctx, frame);
+    if (rc) return rc;
+  }
   int *d_gate = (int *)ctx->scratch + gate_off;
   VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
   VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));

@@ -41,6 +41,7 @@ extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->resid) (void)hipFree(ctx->resid);
   if (ctx->d_taps) (void)hipFree(ctx->d_taps);
   if (ctx->stream2) {
     (void)hipStreamSynchronize(ctx->stream2);

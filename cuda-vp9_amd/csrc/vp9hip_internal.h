@@ -23,6 +23,9 @@ struct vp9hip_ctx {
   // overlap of the intra island walk with the loop filter (vp9hip_intra_islands_lf)
   hipStream_t stream2;
   hipEvent_t ev_fork, ev_join;
+  // residual of the intra island tasks, computed ahead of the walk (intra_kernels.hip): int32 per sample
+  void *resid;
+  size_t resid_bytes;
 };
 
 #define VP9HIP_FAIL(ctx, code, ...)                          \
@@ -76,6 +79,7 @@ static inline int frame_ok(const vp9hip_frame *f) {
 }
 
 int vp9hip_ensure_scratch(vp9hip_ctx *ctx, size_t bytes);
+int vp9hip_ensure_resid(vp9hip_ctx *ctx, const vp9hip_frame *frame);
 int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
                           const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_sb_done, int sb_cols);
