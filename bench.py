@@ -198,6 +198,9 @@ def main():
                 e = pmc.get(k)
                 if e and traffic is not None:
                     v["hbm_traffic_bytes_pmc"] = int(e["hbm_read_bytes_gfx950_x2"] + e["hbm_write_bytes"])
+                    e2 = pmc.get(k + "_residual")  # the intra phase is two kernels: residual pre-pass + walk
+                    if e2:
+                        v["hbm_traffic_bytes_pmc"] += int(e2["hbm_read_bytes_gfx950_x2"] + e2["hbm_write_bytes"])
                     if "lds_bank_conflict_frac" in e:
                         v["lds_bank_conflict_frac_pmc"] = e["lds_bank_conflict_frac"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS,

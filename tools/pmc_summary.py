@@ -12,7 +12,7 @@ import os
 import sys
 
 FAMILY = (("inter_fast_kernel", "convolve"), ("inter_fast16_kernel", "convolve"), ("inter_reg_kernel", "convolve"), ("inter_pred_kernel", "convolve_generic"), ("idct_add", "idct_add"),
-          ("intra_island_kernel", "intra"), ("intra_wave_kernel", "intra_waves"), ("lf_rows", "loop_filter"),
+          ("intra_island_kernel", "intra"), ("intra_residual_kernel", "intra_residual"), ("intra_wave_kernel", "intra_waves"), ("lf_rows", "loop_filter"),
           ("lf_diag", "loop_filter_diag"), ("residual_", "residual"))
 
 

@@ -13,6 +13,9 @@ ap.add_argument("--phase", default="inter")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--width", type=int, default=2560)
 ap.add_argument("--height", type=int, default=1440)
+ap.add_argument("--no-overlap", action="store_true",
+                help="intra and loop filter in sequence: rocprofv3 --pmc runs one kernel at a time, and the "
+                     "overlapped pair (the filter polls counters the island walk raises) needs both resident")
 args = ap.parse_args()
 import __graft_entry__ as g  # noqa: E402
 pkg = g.load_pkg()
@@ -21,6 +24,8 @@ import cuda_vp9_amd.workload as workload  # noqa: E402
 ctx = pkg.Context(0)
 wl = workload.make_frame_workload(args.width, args.height, seed=1440)
 job = pipeline.FrameJob(ctx, wl)
+if args.no_overlap:
+    job.overlap = False
 job.run()            # full frame once so that every phase has realistic input
 ctx.sync()
 phases = ("inter", "txb", "intra", "lf") if args.phase == "all" else (args.phase,)
