@@ -501,7 +501,7 @@ __device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9h
 // touches columns left of 64(c+1).  Waiting only for that, and only before the horizontal pass,
 // halves the lag between superblock rows from two superblock steps to one
 // (critical path cols + rows instead of cols + 2*rows).
-template <typename Pix, int N>
+template <typename Pix, int N, int SH>
 __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const vp9hip_lfm *__restrict__ lfms,
                                              int sb_cols, int sr, int pl, const LfThreshDev &th, const FrameDev &f,
                                              int mi_rows, int *vprog_prev, int *hprog_prev, int *vprog_mine,
@@ -516,7 +516,9 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   constexpr int KA = (8 * DPR + 63) / 64;
   constexpr int TILE = 72 * TP;  // samples per tile buffer
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sh = sizeof(Pix) == 1 ? 0 : f.bit_depth - 8;  // 8-bit samples: a constant, so the clamps fold to v_med3
+  // sample shift of the thresholds: a compile-time constant per bit depth (SH >= 0), so that the
+  // threshold unpacking and the clamps of the narrow filter fold (v_med3, byte-select operands)
+  const int sh = SH >= 0 ? SH : f.bit_depth - 8;
   Pix *plane = (Pix *)f.plane[pl];
   const int stride = f.stride[pl];
   const int pw = f.awidth[pl], ph = f.aheight[pl];
@@ -707,7 +709,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   if (wave == 3) bulk_writeback(ncols - 1);
 }
 
-template <typename Pix>
+template <typename Pix, int SH>
 __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                                        LfThreshDev th, FrameDev f, int mi_rows, int *progress,
                                                        int *err, const int *gate_done, const int *gate_expected) {
@@ -720,10 +722,10 @@ __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restr
   int *hmine = progress + pl * sb_rows + sr;
   int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
   if (pl == 0)
-    lf_row2_body<Pix, 64>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
+    lf_row2_body<Pix, 64, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
                           gate_done, gate_expected, sb_rows);
   else
-    lf_row2_body<Pix, 32>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
+    lf_row2_body<Pix, 32, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
                           gate_done, gate_expected, sb_rows);
 }
 
@@ -773,12 +775,18 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
     if (!counters_zeroed) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, st));
     ctx->lf_err_flag = err;
     if (mode == 2) {
-      if (frame->hbd)
-        hipLaunchKernelGGL(lf_rows2_kernel<uint16_t>, dim3(sb_rows, planes), dim3(256), 0, st, d_lfm, sb_cols,
-                           sb_rows, th, f, mi_rows, progress, err, d_gate, d_sb_expected);
+#define LF_ROWS2(PIX, SH)                                                                                       \
+  hipLaunchKernelGGL((lf_rows2_kernel<PIX, SH>), dim3(sb_rows, planes), dim3(256), 0, st, d_lfm, sb_cols, sb_rows, \
+                     th, f, mi_rows, progress, err, d_gate, d_sb_expected)
+      if (!frame->hbd)
+        LF_ROWS2(uint8_t, 0);
+      else if (frame->bit_depth == 10)
+        LF_ROWS2(uint16_t, 2);
+      else if (frame->bit_depth == 12)
+        LF_ROWS2(uint16_t, 4);
       else
-        hipLaunchKernelGGL(lf_rows2_kernel<uint8_t>, dim3(sb_rows, planes), dim3(256), 0, st, d_lfm, sb_cols,
-                           sb_rows, th, f, mi_rows, progress, err, d_gate, d_sb_expected);
+        LF_ROWS2(uint16_t, 0);
+#undef LF_ROWS2
     } else if (frame->hbd)
       hipLaunchKernelGGL(lf_rows_kernel<uint16_t>, dim3(sb_rows, planes), dim3(64), 0, st, d_lfm, sb_cols,
                          sb_rows, th, f, mi_rows, progress, err);
