@@ -46,6 +46,10 @@ __device__ __forceinline__ int sclamp(int t, int lo, int hi) { return t < lo ? l
 // (only w[4..11] are touched unless kind == 16).  kind 0 = no filter here.
 // vpx_dsp/loopfilter.c: filter_mask :33, flat_mask4 :49, flat_mask5 :62, hev_mask :72,
 // filter4 :76, filter8 :162, filter16 :235; highbd forms :359-447 (thresholds << (bd-8)).
+// WIDE = false: the interior 4x4 edge, whose kind is 0 or 4 — no flat tests, no wide forms in its code
+// (the kernel sits at the edge of the 64 KB instruction cache: two positions per trip in the
+// horizontal pass, +5 k instructions, cost 609 -> 825 us).
+template <bool WIDE>
 __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned thr3, int sh) {
   // w + q points at q0 (q = 8 for the block edge, 12 for the interior 4x4 edge)
   if (kind == 0) return;
@@ -58,9 +62,9 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
   const bool mask = !(m > lim || iabsd(p0, q0) * 2 + (iabsd(p1, q1) >> 1) > blim);
   if (!mask) return;  // every filter form leaves the samples unchanged when the mask is off
   bool flat = false;
-  if (kind >= 8)
+  if (WIDE && kind >= 8)
     flat = max(max(max(d10, e10), max(iabsd(p2, p0), iabsd(q2, q0))), max(iabsd(p3, p0), iabsd(q3, q0))) <= one;
-  if (flat) {
+  if (WIDE && flat) {
     if (kind == 16) {
       const int p4 = w[q - 5], p5 = w[q - 6], p6 = w[q - 7], p7 = w[q - 8];
       const int q4 = w[q + 4], q5 = w[q + 5], q6 = w[q + 6], q7 = w[q + 7];
@@ -101,7 +105,7 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
   const int hev = (d10 > thr || e10 > thr) ? -1 : 0;
   const int ps1 = p1 - off, ps0 = p0 - off, qs0 = q0 - off, qs1 = q1 - off;
   int f = sclamp(ps1 - qs1, lo, hi) & hev;
-  f = sclamp(f + 3 * (qs0 - ps0), lo, hi);
+  f = sclamp(f + __mul24(qs0 - ps0, 3), lo, hi);  // v_mad_i32_i24 (3 * x + f selected the half-rate v_mad_u64_u32)
   const int f1 = sclamp(f + 4, lo, hi) >> 3, f2 = sclamp(f + 3, lo, hi) >> 3;
   w[q] = sclamp(qs0 - f1, lo, hi) + off;
   w[q - 1] = sclamp(ps0 + f2, lo, hi) + off;
@@ -213,8 +217,8 @@ __device__ __forceinline__ void lf_pass_v(Pix *tile, const unsigned *ctl, int y0
 #pragma unroll
       for (int k = 0; k < 8; ++k) nxt[k] = row[8 + cn * 8 + k];
       const unsigned nE = vE[mr * ncol + cn], nI = vI[mr * ncol + cn];
-      filter_window(w, 8, cE >> 24, cE, sh);
-      filter_window(w, 12, cI >> 24, cI, sh);
+      filter_window<true>(w, 8, cE >> 24, cE, sh);
+      filter_window<false>(w, 12, cI >> 24, cI, sh);
 #pragma unroll
       for (int k = 0; k < 8; ++k) row[c * 8 + k] = (Pix)w[k];
 #pragma unroll
@@ -250,8 +254,8 @@ __device__ __forceinline__ void lf_pass_h(Pix *tile, const unsigned *ctl, int x0
 #pragma unroll
       for (int k = 0; k < 8; ++k) nxt[k] = col[(8 + mn * 8 + k) * TP];
       const unsigned nE = hE[mn * ncol + c], nI = hI[mn * ncol + c];
-      filter_window(w, 8, cE >> 24, cE, sh);
-      filter_window(w, 12, cI >> 24, cI, sh);
+      filter_window<true>(w, 8, cE >> 24, cE, sh);
+      filter_window<false>(w, 12, cI >> 24, cI, sh);
 #pragma unroll
       for (int k = 0; k < 8; ++k) col[(mr * 8 + k) * TP] = (Pix)w[k];
 #pragma unroll
