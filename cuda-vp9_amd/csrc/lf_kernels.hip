@@ -46,9 +46,7 @@ __device__ __forceinline__ int sclamp(int t, int lo, int hi) { return t < lo ? l
 // (only w[4..11] are touched unless kind == 16).  kind 0 = no filter here.
 // vpx_dsp/loopfilter.c: filter_mask :33, flat_mask4 :49, flat_mask5 :62, hev_mask :72,
 // filter4 :76, filter8 :162, filter16 :235; highbd forms :359-447 (thresholds << (bd-8)).
-// WIDE = false: the interior 4x4 edge, whose kind is 0 or 4 — no flat tests, no wide forms in its code
-// (the kernel sits at the edge of the 64 KB instruction cache: two positions per trip in the
-// horizontal pass, +5 k instructions, cost 609 -> 825 us).
+// WIDE = false: the interior 4x4 edge, whose kind is 0 or 4 — no flat tests, no wide forms in its code.
 template <bool WIDE>
 __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned thr3, int sh) {
   // w + q points at q0 (q = 8 for the block edge, 12 for the interior 4x4 edge)
@@ -249,8 +247,8 @@ __device__ __forceinline__ void lf_pass_h(Pix *tile, const unsigned *ctl, int x0
 #pragma unroll
     for (int k = 0; k < 16; ++k) w[k] = col[k * TP];
     unsigned cE = hE[c], cI = hI[c];
-    // two positions per trip (the compiler renames the window instead of moving it: 587 -> 568 us); four
-    // would push the kernel past the 64 KB instruction cache
+    // two positions per trip: the compiler renames the window instead of moving it (587 -> 568 us; four
+    // per trip measures the same)
 #pragma unroll 2
     for (int mr = 0; mr < mrows; ++mr) {
       const int mn = mr + 1 < mrows ? mr + 1 : mr;
