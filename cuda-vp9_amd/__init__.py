@@ -417,6 +417,14 @@ class Context:
             ctypes.c_void_p(d_wave_off.ptr), ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
             ctypes.byref(frame.desc)))
 
+    def intra_residual_begin(self, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame):
+        """Optional head start of the island calls (vp9hip_intra_residual_begin): call before the frame's
+        convolve / transform launches with the lists the island call will get."""
+        self.check(lib().vp9hip_intra_residual_begin(
+            self.handle, ctypes.c_void_p(d_tasks.ptr), ctypes.c_void_p(d_islands.ptr), int(n_islands),
+            ctypes.c_void_p(d_wave_off.ptr), ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
+            ctypes.byref(frame.desc)))
+
     def intra_islands_lf(self, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, d_sb_expected, d_lfm, sb_rows,
                          sb_cols, thresh, frame, planes=3):
         """Island walk and loop filter side by side (vp9hip_intra_islands_lf)."""

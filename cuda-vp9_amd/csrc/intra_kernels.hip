@@ -603,42 +603,84 @@ int vp9hip_ensure_resid(vp9hip_ctx *ctx, const vp9hip_frame *frame) {
   return VP9HIP_OK;
 }
 
+static ResidDev resid_dev(vp9hip_ctx *ctx, const vp9hip_frame *frame) {
+  ResidDev rd;
+  memset(&rd, 0, sizeof(rd));
+  rd.p = (int *)ctx->resid;
+  int acc = 0;
+  for (int pl = 0; pl < 3; ++pl) {
+    rd.off[pl] = acc;
+    rd.stride[pl] = frame->awidth[pl];
+    if (frame->plane[pl]) acc += frame->awidth[pl] * frame->aheight[pl];
+  }
+  return rd;
+}
+
+static int residual_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
+                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
+                           const int32_t *d_coeffs, const vp9hip_frame *frame) {
+  const FrameDev f = to_dev(frame);
+  const ResidDev rd = resid_dev(ctx, frame);
+  if (frame->hbd)
+    hipLaunchKernelGGL((intra_residual_kernel<true>), dim3(n_islands, RESID_Y), dim3(256), 0, st, d_tasks, d_islands,
+                       d_wave_off, d_coeffs, rd, f);
+  else
+    hipLaunchKernelGGL((intra_residual_kernel<false>), dim3(n_islands, RESID_Y), dim3(256), 0, st, d_tasks, d_islands,
+                       d_wave_off, d_coeffs, rd, f);
+  VP9HIP_CHECK(ctx, hipGetLastError());
+  return VP9HIP_OK;
+}
+
+// Optional head start (include/vp9hip.h): the pre-pass reads the lists and the coefficients only, so it
+// can run beside the frame's convolve and transforms.  It goes to the context's second stream, ordered
+// after everything enqueued so far (the uploads of its inputs); the island launch of the same lists
+// waits for it instead of running it.
+extern "C" int vp9hip_intra_residual_begin(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
+                                           const vp9hip_intra_island *d_islands, int n_islands,
+                                           const int32_t *d_wave_off, const int32_t *d_coeffs,
+                                           const vp9hip_frame *frame) {
+  if (!ctx) return VP9HIP_EINVAL;
+  VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !frame_ok(frame))
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_residual_begin: bad argument");
+  ctx->resid_tasks = nullptr;
+  if (n_islands == 0 || !d_coeffs) return VP9HIP_OK;
+  int rc = vp9hip_ensure_resid(ctx, frame);
+  if (rc) return rc;
+  if (!ctx->stream2) VP9HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  if (!ctx->ev_resid_start) {
+    VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_resid_start, hipEventDisableTiming));
+    VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_resid_done, hipEventDisableTiming));
+  }
+  VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_resid_start, ctx->stream));
+  VP9HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_resid_start, 0));
+  rc = residual_launch(ctx, ctx->stream2, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
+  if (rc) return rc;
+  VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_resid_done, ctx->stream2));
+  ctx->resid_tasks = d_tasks;
+  ctx->resid_coeffs = d_coeffs;
+  return VP9HIP_OK;
+}
+
 int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
                           const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_sb_done, int sb_cols) {
   const FrameDev f = to_dev(frame);
-  static const bool no_res = getenv("VP9HIP_INTRA_RES") && atoi(getenv("VP9HIP_INTRA_RES")) == 0;
   ResidDev rd;
   memset(&rd, 0, sizeof(rd));
-  if (no_res) {
-    if (frame->hbd)
-      hipLaunchKernelGGL((intra_island_kernel<uint16_t, true, false>), dim3(n_islands), dim3(256), 0, st, d_tasks,
-                         d_islands, d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);
-    else
-      hipLaunchKernelGGL((intra_island_kernel<uint8_t, false, false>), dim3(n_islands), dim3(256), 0, st, d_tasks,
-                         d_islands, d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);
-    VP9HIP_CHECK(ctx, hipGetLastError());
-    return VP9HIP_OK;
-  }
   if (d_coeffs) {
     // the inverse transforms of every coded task, in parallel, ahead of the dependent walk
     int rc = vp9hip_ensure_resid(ctx, frame);
     if (rc) return rc;
-    rd.p = (int *)ctx->resid;
-    int acc = 0;
-    for (int pl = 0; pl < 3; ++pl) {
-      rd.off[pl] = acc;
-      rd.stride[pl] = frame->awidth[pl];
-      if (frame->plane[pl]) acc += frame->awidth[pl] * frame->aheight[pl];
+    rd = resid_dev(ctx, frame);
+    if (ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs) {
+      VP9HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_resid_done, 0));  // vp9hip_intra_residual_begin did it
+    } else {
+      rc = residual_launch(ctx, st, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
+      if (rc) return rc;
     }
-    if (frame->hbd)
-      hipLaunchKernelGGL((intra_residual_kernel<true>), dim3(n_islands, RESID_Y), dim3(256), 0, st, d_tasks, d_islands,
-                         d_wave_off, d_coeffs, rd, f);
-    else
-      hipLaunchKernelGGL((intra_residual_kernel<false>), dim3(n_islands, RESID_Y), dim3(256), 0, st, d_tasks, d_islands,
-                         d_wave_off, d_coeffs, rd, f);
-    VP9HIP_CHECK(ctx, hipGetLastError());
   }
+  ctx->resid_tasks = nullptr;
   if (frame->hbd)
     hipLaunchKernelGGL((intra_island_kernel<uint16_t, true, true>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
                        d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);

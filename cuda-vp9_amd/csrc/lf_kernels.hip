@@ -847,8 +847,8 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
   if (sb_rows > 255 || sb_cols > 255 || sb_rows * sb_cols > VP9HIP_GATE_INTS)
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: frame too large (%d x %d superblocks)", sb_cols, sb_rows);
   if (n_islands == 0) return lf_launch(ctx, ctx->stream, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, nullptr, nullptr);
-  if (!ctx->stream2) {
-    VP9HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  if (!ctx->stream2) VP9HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  if (!ctx->ev_fork) {
     VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   }

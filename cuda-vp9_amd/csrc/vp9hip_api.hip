@@ -40,13 +40,19 @@ extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->resid) (void)hipFree(ctx->resid);
+  if (ctx->ev_resid_start) {
+    (void)hipEventDestroy(ctx->ev_resid_start);
+    (void)hipEventDestroy(ctx->ev_resid_done);
+  }
   if (ctx->d_taps) (void)hipFree(ctx->d_taps);
   if (ctx->stream2) {
-    (void)hipStreamSynchronize(ctx->stream2);
-    (void)hipEventDestroy(ctx->ev_fork);
-    (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_fork) {
+      (void)hipEventDestroy(ctx->ev_fork);
+      (void)hipEventDestroy(ctx->ev_join);
+    }
     (void)hipStreamDestroy(ctx->stream2);
   }
   if (ctx->ev_begin) {

@@ -366,6 +366,13 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
   hipStream_t st = dec->ctx->stream;
   DEC_CTX(dec, vp9hip_timer_begin(dec->ctx, TIMER_RUN));
 
+  // coefficient mode: the island tasks' inverse transforms only need the coefficients — they start beside
+  // the convolve and the inter transforms (in residual-plane mode the residual is gathered later)
+  if ((phases & VP9HIP_PHASE_INTER) && (phases & VP9HIP_PHASE_INTRA) && P->n_islands && dec->have_coeffs && !dec->have_res)
+    DEC_CTX(dec, vp9hip_intra_residual_begin(dec->ctx, (const vp9hip_intra_task *)dec->d_isl_tasks.p,
+                                             (const vp9hip_intra_island *)dec->d_islands.p, P->n_islands,
+                                             (const int32_t *)dec->d_wave_off.p, (const int32_t *)dec->d_coeffs.p, dst));
+
   if ((phases & VP9HIP_PHASE_INTER)) {
     if (P->n_inter) {
       vp9hip_frame refs[3];

@@ -26,6 +26,9 @@ struct vp9hip_ctx {
   // residual of the intra island tasks, computed ahead of the walk (intra_kernels.hip): int32 per sample
   void *resid;
   size_t resid_bytes;
+  // vp9hip_intra_residual_begin: the pre-pass already runs on stream2 for these lists; the walk waits for it
+  hipEvent_t ev_resid_start, ev_resid_done;
+  const void *resid_tasks, *resid_coeffs;
 };
 
 #define VP9HIP_FAIL(ctx, code, ...)                          \

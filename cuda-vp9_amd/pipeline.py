@@ -44,6 +44,11 @@ class FrameJob:
 
     def run(self, phases=("inter", "txb", "intra", "lf")):
         wl, ctx = self.wl, self.ctx
+        # the island tasks' inverse transforms need the coefficients only: they start beside the convolve
+        if ("intra" in phases and self.use_islands and self.d_islands is not None and len(phases) > 1
+                and self.d_coeffs is not None):
+            ctx.intra_residual_begin(self.d_isl_tasks, self.d_islands, len(wl["intra_islands"]), self.d_isl_woff,
+                                     self.d_coeffs, self.dst)
         if "inter" in phases and self.d_inter is not None:
             ctx.inter_pred_batch(self.d_inter, self.inter_counts, self.refs, self.dst)
         if "txb" in phases and self.d_txb is not None:

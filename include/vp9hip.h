@@ -194,6 +194,16 @@ int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
                               const vp9hip_intra_island *d_islands, int n_islands,
                               const int32_t *d_wave_off /* DEVICE */, const int32_t *d_coeffs,
                               const vp9hip_frame *frame);
+/* Optional head start for the island calls (vp9hip_intra_pred_islands / vp9hip_intra_islands_lf): the
+ * inverse transforms of the island tasks depend on the coefficients only, so they can run beside the
+ * frame's convolve and transform launches.  Call it BEFORE those, with the arguments the island call
+ * of the same frame will get; it runs on a second stream inside the context, ordered after everything
+ * enqueued so far, into context-owned scratch, and the island call waits for it.  Skipping the call
+ * only costs the overlap. */
+int vp9hip_intra_residual_begin(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
+                                const vp9hip_intra_island *d_islands, int n_islands,
+                                const int32_t *d_wave_off /* DEVICE */, const int32_t *d_coeffs,
+                                const vp9hip_frame *frame);
 
 /* ------------------------------------------------------------------------------------------
  * (a11–a12) loop filter of a whole frame.  Per 64x64 superblock one vp9hip_lfm record (the
