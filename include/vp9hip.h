@@ -199,7 +199,8 @@ int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
  * frame's convolve and transform launches.  Call it BEFORE those, with the arguments the island call
  * of the same frame will get; it runs on a second stream inside the context, ordered after everything
  * enqueued so far, into context-owned scratch, and the island call waits for it.  Skipping the call
- * only costs the overlap. */
+ * only costs the overlap.  A begin is consumed by the NEXT island call on the context with the same
+ * d_tasks / d_coeffs pointers, so do not change the contents of those buffers in between. */
 int vp9hip_intra_residual_begin(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
                                 const vp9hip_intra_island *d_islands, int n_islands,
                                 const int32_t *d_wave_off /* DEVICE */, const int32_t *d_coeffs,
