@@ -57,7 +57,8 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
   const int q0 = w[q], q1 = w[q + 1], q2 = w[q + 2], q3 = w[q + 3];
   const int d10 = iabsd(p1, p0), e10 = iabsd(q1, q0);
   const int m = max(max(max(iabsd(p3, p2), iabsd(p2, p1)), max(d10, e10)), max(iabsd(q2, q1), iabsd(q3, q2)));
-  const bool mask = !(m > lim || iabsd(p0, q0) * 2 + (iabsd(p1, q1) >> 1) > blim);
+  // '&' not '&&': one execution-mask region instead of two nested ones (568 -> 550 us)
+  const bool mask = (m <= lim) & (iabsd(p0, q0) * 2 + (iabsd(p1, q1) >> 1) <= blim);
   if (!mask) return;  // every filter form leaves the samples unchanged when the mask is off
   bool flat = false;
   if (WIDE && kind >= 8)
