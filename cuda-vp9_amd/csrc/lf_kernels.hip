@@ -61,14 +61,16 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
   const bool mask = (m <= lim) & (iabsd(p0, q0) * 2 + (iabsd(p1, q1) >> 1) <= blim);
   if (!mask) return;  // every filter form leaves the samples unchanged when the mask is off
   bool flat = false;
-  if (WIDE && kind >= 8)
-    flat = max(max(max(d10, e10), max(iabsd(p2, p0), iabsd(q2, q0))), max(iabsd(p3, p0), iabsd(q3, q0))) <= one;
+  if (WIDE)  // evaluated for every lane of the mask region: a region of its own for kind >= 8 costs more than it saves
+    flat = (kind >= 8) &
+           (max(max(max(d10, e10), max(iabsd(p2, p0), iabsd(q2, q0))), max(iabsd(p3, p0), iabsd(q3, q0))) <= one);
   if (WIDE && flat) {
-    if (kind == 16) {
+    {
       const int p4 = w[q - 5], p5 = w[q - 6], p6 = w[q - 7], p7 = w[q - 8];
       const int q4 = w[q + 4], q5 = w[q + 5], q6 = w[q + 6], q7 = w[q + 7];
-      const bool flat2 = max(max(max(iabsd(p4, p0), iabsd(q4, q0)), max(iabsd(p5, p0), iabsd(q5, q0))),
-                             max(max(iabsd(p6, p0), iabsd(q6, q0)), max(iabsd(p7, p0), iabsd(q7, q0)))) <= one;
+      const bool flat2 = (kind == 16) &
+                         (max(max(max(iabsd(p4, p0), iabsd(q4, q0)), max(iabsd(p5, p0), iabsd(q5, q0))),
+                              max(max(iabsd(p6, p0), iabsd(q6, q0)), max(iabsd(p7, p0), iabsd(q7, q0)))) <= one);
       if (flat2) {
         // 15-tap [1 1 1 1 1 1 1 2 1 1 1 1 1 1 1], replication at p7 / q7: sliding sum
         int s = p7 * 7 + p6 * 2 + p5 + p4 + p3 + p2 + p1 + p0 + q0 + 8;
@@ -101,7 +103,7 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
   }
   // narrow filter (filter4)
   const int off = 0x80 << sh, lo = -off, hi = off - 1;
-  const int hev = (d10 > thr || e10 > thr) ? -1 : 0;
+  const int hev = ((d10 > thr) | (e10 > thr)) ? -1 : 0;
   const int ps1 = p1 - off, ps0 = p0 - off, qs0 = q0 - off, qs1 = q1 - off;
   int f = sclamp(ps1 - qs1, lo, hi) & hev;
   f = sclamp(f + __mul24(qs0 - ps0, 3), lo, hi);  // v_mad_i32_i24 (3 * x + f selected the half-rate v_mad_u64_u32)
