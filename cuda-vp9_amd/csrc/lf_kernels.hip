@@ -50,7 +50,10 @@ __device__ __forceinline__ int sclamp(int t, int lo, int hi) { return t < lo ? l
 template <bool WIDE>
 __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned thr3, int sh) {
   // w + q points at q0 (q = 8 for the block edge, 12 for the interior 4x4 edge)
-  if (kind == 0) return;
+  // Interior edges are often absent on every line: their evaluation has an early out.  For block edges "no
+  // edge on this line" is one more term of the mask — an early out of its own (execution-mask region, or
+  // a scalar branch on a ballot) measured slower on partitions with small and with large blocks.
+  if (!WIDE && kind == 0) return;
   const int blim = (int)(thr3 & 0xff) << sh, lim = (int)((thr3 >> 8) & 0xff) << sh;
   const int thr = (int)((thr3 >> 16) & 0xff) << sh, one = 1 << sh;
   const int p3 = w[q - 4], p2 = w[q - 3], p1 = w[q - 2], p0 = w[q - 1];
@@ -58,7 +61,7 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
   const int d10 = iabsd(p1, p0), e10 = iabsd(q1, q0);
   const int m = max(max(max(iabsd(p3, p2), iabsd(p2, p1)), max(d10, e10)), max(iabsd(q2, q1), iabsd(q3, q2)));
   // '&' not '&&': one execution-mask region instead of two nested ones (568 -> 550 us)
-  const bool mask = (m <= lim) & (iabsd(p0, q0) * 2 + (iabsd(p1, q1) >> 1) <= blim);
+  const bool mask = (kind != 0) & (m <= lim) & (iabsd(p0, q0) * 2 + (iabsd(p1, q1) >> 1) <= blim);
   if (!mask) return;  // every filter form leaves the samples unchanged when the mask is off
   bool flat = false;
   if (WIDE)  // evaluated for every lane of the mask region: a region of its own for kind >= 8 costs more than it saves
