@@ -105,17 +105,18 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
     return;
   }
   // narrow filter (filter4)
-  const int off = 0x80 << sh, lo = -off, hi = off - 1;
+  // libvpx works on samples offset by -0x80 << sh (signed chars): the offsets cancel in the differences,
+  // and clamp(x - off, -off, off - 1) + off == clamp(x, 0, 2 * off - 1) for the four results
+  const int off = 0x80 << sh, lo = -off, hi = off - 1, maxv = 2 * off - 1;
   const int hev = ((d10 > thr) | (e10 > thr)) ? -1 : 0;
-  const int ps1 = p1 - off, ps0 = p0 - off, qs0 = q0 - off, qs1 = q1 - off;
-  int f = sclamp(ps1 - qs1, lo, hi) & hev;
-  f = sclamp(f + __mul24(qs0 - ps0, 3), lo, hi);  // v_mad_i32_i24 (3 * x + f selected the half-rate v_mad_u64_u32)
+  int f = sclamp(p1 - q1, lo, hi) & hev;
+  f = sclamp(f + __mul24(q0 - p0, 3), lo, hi);  // v_mad_i32_i24 (3 * x + f selected the half-rate v_mad_u64_u32)
   const int f1 = sclamp(f + 4, lo, hi) >> 3, f2 = sclamp(f + 3, lo, hi) >> 3;
-  w[q] = sclamp(qs0 - f1, lo, hi) + off;
-  w[q - 1] = sclamp(ps0 + f2, lo, hi) + off;
+  w[q] = sclamp(q0 - f1, 0, maxv);
+  w[q - 1] = sclamp(p0 + f2, 0, maxv);
   f = ((f1 + 1) >> 1) & ~hev;
-  w[q + 1] = sclamp(qs1 - f, lo, hi) + off;
-  w[q - 2] = sclamp(ps1 + f, lo, hi) + off;
+  w[q + 1] = sclamp(q1 - f, 0, maxv);
+  w[q - 2] = sclamp(p1 + f, 0, maxv);
 }
 
 
