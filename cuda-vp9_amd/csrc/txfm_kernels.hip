@@ -118,19 +118,36 @@ struct TxPlan {
   int count[4];
 };
 
+// XCD-aware order inside a size class (same idea as the convolve, inter_kernels.hip): workgroup b runs
+// on XCD b % 8 and each XCD has its own L2; records are in decode (superblock-raster) order, so handing
+// XCD x the x-th contiguous eighth of a class keeps blocks that share destination cache lines (4x4 and
+// 8x8 blocks write 4- and 8-byte row pieces) in one L2 instead of fetching the lines once per XCD.
+__device__ __forceinline__ int tx_xcd_order(int b, int s0, int s1) {
+  const int x = b & 7;
+  int prefix = 0, first_x = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int first = s0 + ((j - s0) & 7);  // first workgroup of [s0, s1) on XCD j
+    const int cnt = first < s1 ? (s1 - first + 7) >> 3 : 0;
+    if (j < x) prefix += cnt;
+    if (j == x) first_x = first;
+  }
+  return prefix + ((b - first_x) >> 3);
+}
+
 template <typename Pix, bool HBD>
 __global__ __launch_bounds__(256) void idct_add_all_kernel(const vp9hip_txb *__restrict__ blocks, TxPlan plan,
                                                            const int32_t *__restrict__ coeffs, FrameDev f) {
   __shared__ int lds[TX_LDS_INTS];
   const int b = blockIdx.x;
   if (b < plan.wg_start[1])
-    idct_add_body<4, Pix, HBD>(lds, b - plan.wg_start[0], blocks + plan.blk_start[0], plan.count[0], coeffs, f);
+    idct_add_body<4, Pix, HBD>(lds, tx_xcd_order(b, plan.wg_start[0], plan.wg_start[1]), blocks + plan.blk_start[0], plan.count[0], coeffs, f);
   else if (b < plan.wg_start[2])
-    idct_add_body<8, Pix, HBD>(lds, b - plan.wg_start[1], blocks + plan.blk_start[1], plan.count[1], coeffs, f);
+    idct_add_body<8, Pix, HBD>(lds, tx_xcd_order(b, plan.wg_start[1], plan.wg_start[2]), blocks + plan.blk_start[1], plan.count[1], coeffs, f);
   else if (b < plan.wg_start[3])
-    idct_add_body<16, Pix, HBD>(lds, b - plan.wg_start[2], blocks + plan.blk_start[2], plan.count[2], coeffs, f);
+    idct_add_body<16, Pix, HBD>(lds, tx_xcd_order(b, plan.wg_start[2], plan.wg_start[3]), blocks + plan.blk_start[2], plan.count[2], coeffs, f);
   else
-    idct_add_body<32, Pix, HBD>(lds, b - plan.wg_start[3], blocks + plan.blk_start[3], plan.count[3], coeffs, f);
+    idct_add_body<32, Pix, HBD>(lds, tx_xcd_order(b, plan.wg_start[3], plan.wg_start[4]), blocks + plan.blk_start[3], plan.count[3], coeffs, f);
 }
 
 }  // namespace
