@@ -621,22 +621,52 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       if (i < 8 * DPR) t32[r * TPD + 8 / PPD + d] = above[k];
     }
   };
-  auto bulk_writeback = [&](int sc) {  // wave 1: everything of superblock sc except the hand-off rows
+  // everything of superblock sc except the hand-off rows; `part` of 2: the upper / lower half of the tile rows
+  // (two waves share it: with one, the filtering wave waited ~2 k cycles per step at the barrier behind its
+  // vertical pass with 8-bit samples and ~9 k with 16-bit samples — twice the bytes)
+  auto bulk_writeback = [&](int sc, int part) {
     const int x0 = sc * n;
     const unsigned *t32 = (const unsigned *)(tiles + (sc & 1) * TILE);
     const bool last = sc == ncols - 1;
-    const int wcols = last ? n + 8 : n;
-    constexpr int wd = (n + 8) / PPD;
-    for (int i = lane; i < n * wd; i += 64) {  // tile rows 0 .. n-1
-      const int r = i / wd, d = i - r * wd;
-      const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
-      if (r < 8 ? (d * PPD < 8) : (d * PPD >= wcols)) continue;
-      if (gx < 0 || gy < 0 || gx >= pw || gy >= ph) continue;
-      unsigned *gp = (unsigned *)(plane + (size_t)gy * stride + gx);
-      if (r < 8)
-        st_sc1(gp, t32[r * TPD + d]);  // rows above: lines shared with row sr-1 (see lf_row_body)
-      else
-        *gp = t32[r * TPD + d];
+    // tile rows 8 .. n-1 (this superblock row's own rows but the bottom 8), tile columns 0 .. n-1: 16-byte
+    // pieces, one per lane — a dword per lane with a division per dword took the wave longer than the
+    // filtering wave's vertical pass
+    constexpr int PXC = 16 / (int)sizeof(Pix);      // samples per piece
+    constexpr int cpr = n / PXC;                     // pieces per row (a power of two)
+    constexpr int tot = (n - 8) * cpr, half = tot / 2;
+    for (int ci = part * half + lane; ci < (part + 1) * half; ci += 64) {
+      const int r = 8 + ci / cpr, c = ci % cpr;
+      const int gx = x0 - 8 + c * PXC, gy = y0 - 8 + r;
+      if (gy >= ph) continue;
+      const unsigned *tp = t32 + r * TPD + c * 4;
+      Pix *gp = plane + (size_t)gy * stride + gx;
+      if (gx >= 0 && gx + PXC <= pw) {
+        uint4 v;
+        v.x = tp[0]; v.y = tp[1]; v.z = tp[2]; v.w = tp[3];
+        __builtin_memcpy(gp, &v, 16);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (gx + k * PPD >= 0 && gx + k * PPD < pw) ((unsigned *)gp)[k] = tp[k];
+      }
+    }
+    if (part == 1 && last) {  // the frame's last superblock of the row: its right strip goes out as well
+      constexpr int ed = 8 / PPD;  // dwords per row
+      for (int i = lane; i < (n - 8) * ed; i += 64) {
+        const int r = 8 + i / ed, d = i % ed;
+        const int gx = x0 - 8 + n + d * PPD, gy = y0 - 8 + r;
+        if (gx < pw && gy < ph) *(unsigned *)(plane + (size_t)gy * stride + gx) = t32[r * TPD + n / PPD + d];
+      }
+    }
+    if (part == 0 && sr > 0) {
+      // tile rows 0..7 (the 8 rows above, which the horizontal pass changed), tile columns 8 .. n+7: lines
+      // shared with row sr-1, write-through (see lf_row_body); their left strip went out a step ago
+      constexpr int ed = n / PPD;  // dwords per row
+      for (int i = lane; i < 8 * ed; i += 64) {
+        const int r = i / ed, d = 8 / PPD + i % ed;
+        const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
+        if (gx < pw) st_sc1((unsigned *)(plane + (size_t)gy * stride + gx), t32[r * TPD + d]);
+      }
     }
   };
   // wave 0: tile rows n..n+7 (the bottom 8 rows of this superblock row), tile columns [c0, c1), out
@@ -686,8 +716,9 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     } else if (wave == 1) {
       fetch_above(sc);
     } else if (wave == 3) {
-      if (sc > 0) bulk_writeback(sc - 1);  // its own wave: twice the bytes with 16-bit samples
+      if (sc > 0) bulk_writeback(sc - 1, 0);
     } else {
+      if (sc > 0) bulk_writeback(sc - 1, 1);  // the publisher is idle until the vertical pass ends
       wait_flag(&flags[0], sc + 1);
       if (sc > 0) handoff(t32, x0, 0, 8);  // the corner the vertical pass completed (drained)
       if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -718,7 +749,8 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     }
     __syncthreads();
   }
-  if (wave == 3) bulk_writeback(ncols - 1);
+  if (wave == 3) bulk_writeback(ncols - 1, 0);
+  if (wave == 2) bulk_writeback(ncols - 1, 1);
 }
 
 template <typename Pix, int SH>
