@@ -682,14 +682,8 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
-  // wave 2 (publisher): waits for wave 0's LDS flag, sends the rows out and publishes the progress
-  // once they have drained — wave 0 never waits for a store.  flags[0]: vertical passes done,
-  // flags[1]: horizontal passes done (monotonic, written by wave 0 lane 0 after its LDS fence).
-  auto wait_flag = [&](volatile unsigned *flag, unsigned need) {
-    while (*flag < need) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  };
-
+  // wave 2 (publisher) sends the hand-off rows out and publishes the progress once they have drained —
+  // wave 0 never waits for a store; the barriers order its LDS reads behind wave 0's passes.
   // the filtering wave is the critical path of the frame: when it shares a SIMD with waves of the
   // island walk running beside it, it issues first
   if (wave == 0) __builtin_amdgcn_s_setprio(3);
@@ -700,7 +694,6 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     load_interior(0);
     store_interior(0);
   }
-  if (threadIdx.x == 0) flags[0] = flags[1] = 0;
   __syncthreads();
   for (int sc = 0; sc < ncols; ++sc) {
     const int x0 = sc * n;
@@ -711,24 +704,23 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     // ---- phase A
     if (wave == 0) {
       lf_pass_v<Pix, N>(tile, ctl, y0, ph, mrows, sh);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) flags[0] = sc + 1;
     } else if (wave == 1) {
       fetch_above(sc);
     } else if (wave == 3) {
       if (sc > 0) bulk_writeback(sc - 1, 0);
-    } else {
-      if (sc > 0) bulk_writeback(sc - 1, 1);  // the publisher is idle until the vertical pass ends
-      wait_flag(&flags[0], sc + 1);
-      if (sc > 0) handoff(t32, x0, 0, 8);  // the corner the vertical pass completed (drained)
-      if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (sc > 0) {
+      // publisher, half a phase behind the filter so that neither barrier waits for its store drains
+      // (they cost the filtering wave ~1.5 k + ~1.9 k cycles per step): while superblock sc gets its
+      // vertical pass, the bottom rows the horizontal pass of sc-1 completed go out (other tile buffer;
+      // that pass ended before barrier B), then its share of the write-back of sc-1
+      handoff((const unsigned *)(tiles + ((sc - 1) & 1) * TILE), x0 - n, 8, n);
+      if (lane == 0) __hip_atomic_store(hprog_mine, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bulk_writeback(sc - 1, 1);
     }
     __syncthreads();
     // ---- phase B + C: wave 0 filters and moves the strip, wave 1 prefetches, wave 2 publishes
     if (wave == 0) {
       lf_pass_h<Pix, N>(tile, ctl, x0, pw, mrows, sh);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) flags[1] = sc + 1;
       // the right strip becomes the left strip of the next superblock (other buffer; its rows
       // 8.. columns 0..7 are not touched by wave 1's interior store)
       if (!last && lane < n) {
@@ -743,14 +735,20 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         store_interior(sc + 1);
       }
     } else if (wave == 2) {
-      wait_flag(&flags[1], sc + 1);
-      handoff(t32, x0, 8, last ? n + 8 : n);
-      if (lane == 0) __hip_atomic_store(hprog_mine, last ? sb_cols : sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // ... and while superblock sc gets its horizontal pass (tile columns 8..), the 8x8 corner its vertical
+      // pass completed (tile columns 0..7: final now; that pass ended before barrier A) goes out.  Same wave,
+      // drained in between: the corner lands after the rows of sc-1 it overwrites.
+      if (sc > 0) handoff(t32, x0, 0, 8);
+      if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
+  if (wave == 2) {  // the last superblock's bottom rows, right strip included
+    handoff((const unsigned *)(tiles + ((ncols - 1) & 1) * TILE), (ncols - 1) * n, 8, n + 8);
+    if (lane == 0) __hip_atomic_store(hprog_mine, sb_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bulk_writeback(ncols - 1, 1);
+  }
   if (wave == 3) bulk_writeback(ncols - 1, 0);
-  if (wave == 2) bulk_writeback(ncols - 1, 1);
 }
 
 template <typename Pix, int SH>
