@@ -203,7 +203,8 @@ __device__ __forceinline__ void lf_tile_sync() {
 
 // ---- vertical edges: lane = sample row; a 16-sample window slides along the row
 template <typename Pix, int N>
-__device__ __forceinline__ void lf_pass_v(Pix *tile, const unsigned *ctl, int y0, int ph, int mrows, int sh) {
+__device__ __forceinline__ void lf_pass_v(Pix *tile, const unsigned *ctl, int y0, int ph, int mrows, int sh,
+                                          volatile unsigned *strip_flag = nullptr, unsigned strip_val = 0) {
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int n = N;
   constexpr int ncol = N / 8;
@@ -226,6 +227,12 @@ __device__ __forceinline__ void lf_pass_v(Pix *tile, const unsigned *ctl, int y0
       filter_window<false>(w, 12, cI >> 24, cI, sh);
 #pragma unroll
       for (int k = 0; k < 8; ++k) row[c * 8 + k] = (Pix)w[k];
+      if (c == 0 && strip_flag != nullptr) {
+        // the left strip (the last 8 columns of the superblock before) is final after the first position:
+        // tell the publisher wave now, so that the row below gets the corner ~7/8 of a pass earlier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) *strip_flag = strip_val;
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         w[k] = w[8 + k];
@@ -694,6 +701,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     load_interior(0);
     store_interior(0);
   }
+  if (threadIdx.x == 0) flags[0] = 0;
   __syncthreads();
   for (int sc = 0; sc < ncols; ++sc) {
     const int x0 = sc * n;
@@ -703,19 +711,28 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     const unsigned *ctl = ctls + (sc & 1) * 256;
     // ---- phase A
     if (wave == 0) {
-      lf_pass_v<Pix, N>(tile, ctl, y0, ph, mrows, sh);
+      lf_pass_v<Pix, N>(tile, ctl, y0, ph, mrows, sh, &flags[0], (unsigned)(sc + 1));
+      if (lane == 0) flags[0] = sc + 1;  // (whatever the lanes of the pass did)
     } else if (wave == 1) {
       fetch_above(sc);
     } else if (wave == 3) {
       if (sc > 0) bulk_writeback(sc - 1, 0);
-    } else if (sc > 0) {
-      // publisher, half a phase behind the filter so that neither barrier waits for its store drains
-      // (they cost the filtering wave ~1.5 k + ~1.9 k cycles per step): while superblock sc gets its
-      // vertical pass, the bottom rows the horizontal pass of sc-1 completed go out (other tile buffer;
-      // that pass ended before barrier B), then its share of the write-back of sc-1
-      handoff((const unsigned *)(tiles + ((sc - 1) & 1) * TILE), x0 - n, 8, n);
-      if (lane == 0) __hip_atomic_store(hprog_mine, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bulk_writeback(sc - 1, 1);
+    } else {
+      // publisher: neither barrier waits for its store drains (they cost the filtering wave ~1.5 k + ~1.9 k
+      // cycles per step when it sent a pass's rows right behind that pass).  While superblock sc gets its
+      // vertical pass: the bottom rows the horizontal pass of sc-1 completed (other tile buffer; that pass
+      // ended before barrier B); then, as soon as the first position of the vertical pass is through (LDS
+      // flag), the 8x8 corner it completed — same wave, drained in between, so the corner lands after the
+      // rows of sc-1 it overwrites; then its share of the write-back of sc-1.
+      if (sc > 0) {
+        handoff((const unsigned *)(tiles + ((sc - 1) & 1) * TILE), x0 - n, 8, n);
+        if (lane == 0) __hip_atomic_store(hprog_mine, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      while (flags[0] < (unsigned)(sc + 1)) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (sc > 0) handoff(t32, x0, 0, 8);
+      if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sc > 0) bulk_writeback(sc - 1, 1);
     }
     __syncthreads();
     // ---- phase B + C: wave 0 filters and moves the strip, wave 1 prefetches, wave 2 publishes
@@ -734,12 +751,6 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         load_interior(sc + 1);
         store_interior(sc + 1);
       }
-    } else if (wave == 2) {
-      // ... and while superblock sc gets its horizontal pass (tile columns 8..), the 8x8 corner its vertical
-      // pass completed (tile columns 0..7: final now; that pass ended before barrier A) goes out.  Same wave,
-      // drained in between: the corner lands after the rows of sc-1 it overwrites.
-      if (sc > 0) handoff(t32, x0, 0, 8);
-      if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
