@@ -828,8 +828,12 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
     if (!counters_zeroed) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, st));
     ctx->lf_err_flag = err;
     if (mode == 2) {
+// Unused dynamic LDS on top of the kernel's own, so that at most ONE of these workgroups fits a CU (160 KB):
+// a row that waits for islands (vp9hip_intra_islands_lf) must leave the CU's registers to an island
+// workgroup beside it, however many streams are in flight — two filter workgroups on a CU would not.
+#define LF_LDS_PAD(PIX) (84 * 1024 - (int)sizeof(PIX) * 2 * 72 * 76 - 4096)
 #define LF_ROWS2(PIX, SH)                                                                                       \
-  hipLaunchKernelGGL((lf_rows2_kernel<PIX, SH>), dim3(sb_rows, planes), dim3(256), 0, st, d_lfm, sb_cols, sb_rows, \
+  hipLaunchKernelGGL((lf_rows2_kernel<PIX, SH>), dim3(sb_rows, planes), dim3(256), LF_LDS_PAD(PIX), st, d_lfm, sb_cols, sb_rows, \
                      th, f, mi_rows, progress, err, d_gate, d_sb_expected)
       if (!frame->hbd)
         LF_ROWS2(uint8_t, 0);
