@@ -654,6 +654,12 @@ extern "C" int vp9hip_intra_residual_begin(vp9hip_ctx *ctx, const vp9hip_intra_t
   }
   VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_resid_start, ctx->stream));
   VP9HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_resid_start, 0));
+  // the zero-fill of the filter / island counters of vp9hip_intra_islands_lf rides along (4:2:0 or luma only)
+  ctx->lf_zeroed_rows = ctx->lf_zeroed_cols = 0;
+  if (frame->aheight[0] <= 128 * 64 && frame->awidth[0] <= 128 * 64) {
+    rc = vp9hip_lf_zero_counters(ctx, frame, ctx->stream2);
+    if (rc) return rc;
+  }
   rc = residual_launch(ctx, ctx->stream2, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
   if (rc) return rc;
   VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_resid_done, ctx->stream2));

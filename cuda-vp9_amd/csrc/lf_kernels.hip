@@ -880,6 +880,26 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
   return lf_launch(ctx, ctx->stream, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, nullptr, nullptr);
 }
 
+// Layout of the context scratch the overlapped call uses: the filter's progress counters, then (64-int
+// aligned) one island counter per superblock.
+static inline size_t lf_gate_off(int sb_rows) { return ((size_t)(6 * sb_rows + 1) + 63) & ~(size_t)63; }
+static inline size_t lf_counter_bytes(int sb_rows, int sb_cols) {
+  return (lf_gate_off(sb_rows) + (size_t)sb_rows * sb_cols) * sizeof(int);
+}
+
+// Zero-fill of those counters ahead of time (vp9hip_intra_residual_begin, on its stream): one launch less
+// between the transforms and the walk / the filter.
+int vp9hip_lf_zero_counters(vp9hip_ctx *ctx, const vp9hip_frame *frame, hipStream_t st) {
+  const int sb_rows = (frame->aheight[0] + 63) / 64, sb_cols = (frame->awidth[0] + 63) / 64;
+  const size_t need = lf_counter_bytes(sb_rows, sb_cols);
+  int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
+  if (rc) return rc;
+  VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, st));
+  ctx->lf_zeroed_rows = sb_rows;
+  ctx->lf_zeroed_cols = sb_cols;
+  return VP9HIP_OK;
+}
+
 constexpr int VP9HIP_GATE_INTS = 16384;  // island counters: up to 128 x 128 superblocks (8192 x 8192 samples)
 
 // Intra island walk and loop filter side by side: islands on the context's stream, the loop filter
@@ -906,9 +926,8 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
   }
   // one zero-fill for the filter's progress counters and the island counters behind them (scratch must
   // exist before the fork: growing it synchronises)
-  const size_t lf_ints = (size_t)(6 * sb_rows + 1);
-  const size_t gate_off = (lf_ints + 63) & ~(size_t)63;
-  const size_t need = (gate_off + (size_t)sb_rows * sb_cols) * sizeof(int);
+  const size_t gate_off = lf_gate_off(sb_rows);
+  const size_t need = lf_counter_bytes(sb_rows, sb_cols);
   {
     int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
     if (rc) return rc;
@@ -918,7 +937,12 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
     if (rc) return rc;
   }
   int *d_gate = (int *)ctx->scratch + gate_off;
-  VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
+  // the counters were zero-filled by vp9hip_intra_residual_begin of this frame (on stream2, which the filter
+  // follows in order and the walk waits for), or are now
+  const bool zeroed = d_coeffs && ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs &&
+                      ctx->lf_zeroed_rows == sb_rows && ctx->lf_zeroed_cols == sb_cols;
+  ctx->lf_zeroed_rows = ctx->lf_zeroed_cols = 0;
+  if (!zeroed) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
   VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   VP9HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   int rc = vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, d_gate, sb_cols);
