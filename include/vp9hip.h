@@ -198,7 +198,8 @@ int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
  * inverse transforms of the island tasks depend on the coefficients only, so they can run beside the
  * frame's convolve and transform launches.  Call it BEFORE those, with the arguments the island call
  * of the same frame will get; it runs on a second stream inside the context, ordered after everything
- * enqueued so far, into context-owned scratch, and the island call waits for it.  Skipping the call
+ * enqueued so far, into context-owned scratch, and the island call waits for it (the zero-fill of the
+ * counters vp9hip_intra_islands_lf uses rides along).  Skipping the call
  * only costs the overlap.  A begin is consumed by the NEXT island call on the context with the same
  * d_tasks / d_coeffs pointers, so do not change the contents of those buffers in between. */
 int vp9hip_intra_residual_begin(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
