@@ -557,8 +557,12 @@ __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_ta
   // first wavefront carried two blocks in every wave (4800 cycles per wave against 3100 / 1400 / 700 for
   // the other three, in-kernel stamps on the deepest island of the bench frame).
   const int slot = ((threadIdx.x / SLOT) & 1) * (SLOTS / 2) + (threadIdx.x / SLOT) / 2;
-  for (int w = 0; w < isl.n_waves; ++w) {
-    const int begin = wave_off[isl.wave_off_start + w], end = wave_off[isl.wave_off_start + w + 1];
+  // the offsets of a wave are fetched a wave ahead (a scalar load, waited for only when they are used)
+  const int32_t *wo = wave_off + isl.wave_off_start;
+  const int nw = (int)isl.n_waves;
+  int begin = wo[0], end = wo[nw > 0 ? 1 : 0];
+  for (int w = 0; w < nw; ++w) {
+    const int nend = wo[w + 2 <= nw ? w + 2 : nw];
     for (int base = begin; base < end; base += SLOTS) {
       const int ti = base + slot;
       if constexpr (RES)
@@ -588,6 +592,8 @@ __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_ta
         }
       }
     }
+    begin = end;
+    end = nend;
   }
 }
 
