@@ -1,3 +1,4 @@
+#!/bin/bash
 set -e
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc_kc; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
