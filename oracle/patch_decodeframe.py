@@ -22,6 +22,10 @@ Edits (decode_tiles = vp9_decodeframe.c:2303-2639):
       become `if (0)`: the frame wrap_cuda_intra_prediction delivers is already filtered
   E4  initBuf (:2244-2246): no malloc + memset of the frame-sized int64 residual plane
   E5  `X_Fuel(pbi);` (:3567) only for high-bitdepth buffers (it reinterprets the buffer as uint16)
+  E6  `int n = cm->width * cm->height;` (:2314) sizes dqcoeff[plane] (initBuf :2266) and the block
+      lists; coefficient slots cover whole transform blocks, so a frame whose size is not a multiple
+      of 8 (or whose last 32x32 transform block overhangs the frame) overruns it (heap corruption,
+      e.g. 350x286).  n becomes the superblock-aligned area.
 """
 import sys
 
@@ -76,6 +80,10 @@ def main():
                      "  buffer->residuals = NULL; /* residual plane not needed: transforms run behind wrap_cuda_* */\n",
                      "E4 residual malloc")
     t = replace_once(t, "  memset(buffer->residuals, 0, src->frame_size * sizeof(tran_high_t));\n", "", "E4 residual memset")
+
+    # E6
+    t = replace_once(t, "  int n = cm->width * cm->height;\n",
+                     "  int n = 64 * mi_cols_aligned_to_sb(cm->mi_cols) * mi_cols_aligned_to_sb(cm->mi_rows);\n", "E6 n")
 
     # E5
     t = replace_once(t, "    X_Fuel(pbi);\n",

@@ -111,7 +111,7 @@ void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_
 
 void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable) {
   shim_state *s = state_of(pbi, &pbi->common);
-  if (!s) return;
+  if (!s || s->gpu_lf == (enable != 0)) return; /* callers may repeat the call for every frame */
   s->gpu_lf = enable != 0;
   for (int i = 0; i < VP9HIP_POOL_SLOTS; ++i) s->resident[i].valid = 0;
 }

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""tests/golden/streams/make_streams.py — synthesizes the VP9 test streams and their golden MD5 lists.
+
+Runs in the development container only (needs oracle/_ref/vpx/{vpxenc_c,vpxdec_c,vpxdec_cA}, i.e.
+/root/reference + oracle/build_refvpx.sh).  For every stream:
+  1. a seeded synthetic source (band-limited noise translating by (dx, dy) samples per frame, fresh
+     noise patches in some frames to force intra blocks) is written to a scratch file;
+  2. the reference's encoder, linked with the CPU stream oracle as its decoder, encodes it with
+     `--test-decode=fatal`: every frame the oracle decodes is compared with the encoder's own
+     reconstruction, so a stream only gets here if the oracle decodes it exactly;
+  3. the reference's vpxdec (CPU wrap_cuda_* bodies) writes the per-frame MD5 list in vpxdec's
+     `--md5` format (libvpx/vpxdec.c:285-302, 490-495) — the format of Sony.md5 / netflix.md5.
+Small streams (<= ~200 KB) land in tests/golden/streams/ and are committed; the BASELINE.json-sized
+ones (S-1440, S-2160, S-1080-10) land in tests/streams_big/ (git-ignored, travels to the GPU box).
+
+    python3 tests/golden/streams/make_streams.py [--big] [name ...]
+"""
+import hashlib
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+from scipy.ndimage import gaussian_filter
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
+VPX = os.path.join(ROOT, "oracle", "_ref", "vpx")
+BIG = os.path.join(ROOT, "tests", "streams_big")
+
+COMMON = ["--codec=vp9", "--ivf", "--end-usage=q", "--kf-max-dist=9999", "--test-decode=fatal", "--quiet"]
+
+# name: (width, height, frames, seed, dx, dy, bits, chroma, patch_prob, jitter, encoder args, big)
+STREAMS = {
+    # 8-bit 4:2:0, two tile columns, one pass, no lag
+    "s704_8": (704, 576, 8, 704, 5, 3, 8, "420", 0.4, 0, ["--cpu-used=2", "--cq-level=30", "--tile-columns=1", "--lag-in-frames=0", "--passes=1"], False),
+    # odd size (not a multiple of 8), tile rows
+    "s350_8": (350, 286, 8, 350, -3, 2, 8, "420", 0.4, 0, ["--cpu-used=1", "--cq-level=28", "--tile-rows=1", "--lag-in-frames=0", "--passes=1"], False),
+    # two-pass with alt-ref: compound prediction, hidden frames, show_existing_frame
+    "s352_arf": (352, 288, 16, 352, 4, -2, 8, "420", 0.2, 0, ["--good", "--cpu-used=1", "--cq-level=32", "--passes=2", "--auto-alt-ref=1", "--lag-in-frames=12"], False),
+    # 10-bit profile 2, width and height multiples of 64 (the UNCHANGED reference driver reads
+    # size_for_mb out of bounds otherwise, vp9_decodeframe.c:2489-2534)
+    "s704_10": (704, 576, 6, 710, 6, 2, 10, "420", 0.4, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=2", "--cq-level=30", "--tile-columns=1", "--lag-in-frames=0", "--passes=1"], False),
+    # BASELINE.json-sized streams (SURVEY §8d / BASELINE.md §2)
+    "S-1440": (2560, 1440, 60, 1440, 5, 3, 8, "420", 0.1, 0, ["--cpu-used=2", "--cq-level=24", "--tile-columns=3", "--lag-in-frames=0", "--passes=1"], True),
+    "S-2160": (3840, 2160, 30, 2160, 23, -17, 8, "420", 0.0, 8, ["--cpu-used=4", "--cq-level=32", "--tile-columns=4", "--lag-in-frames=0", "--passes=1"], True),
+    "S-1080-10": (1920, 1080, 30, 1080, 7, 4, 10, "420", 0.1, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=2", "--cq-level=28", "--tile-columns=2", "--lag-in-frames=0", "--passes=1"], True),
+}
+
+
+def source(path, w, h, n, seed, dx, dy, bits, chroma, patch_prob, jitter):
+    rng = np.random.default_rng(seed)
+    ss = 1 if chroma == "420" else 0
+    pad = 64 + jitter
+    W, H = w + abs(dx) * n + 2 * pad, h + abs(dy) * n + 2 * pad
+    planes = []
+    for _ in range(3):
+        p = gaussian_filter(rng.uniform(0.0, 1.0, (H, W)).astype(np.float32), 2.0)
+        planes.append((p - p.min()) / (p.max() - p.min()))
+    mx = (1 << bits) - 1
+    dt = np.uint8 if bits == 8 else "<u2"
+    with open(path, "wb") as f:
+        for i in range(n):
+            ox = pad + (dx * i if dx >= 0 else -dx * (n - 1 - i))
+            oy = pad + (dy * i if dy >= 0 else -dy * (n - 1 - i))
+            fr = [planes[0][oy:oy + h, ox:ox + w].copy(),
+                  planes[1][oy:oy + h, ox:ox + w][::1 + ss, ::1 + ss].copy(),
+                  planes[2][oy:oy + h, ox:ox + w][::1 + ss, ::1 + ss].copy()]
+            if jitter and i > 0:  # per-64x64-tile random displacement: incoherent sub-pel motion
+                for ty in range(0, h, 64):
+                    for tx in range(0, w, 64):
+                        jx, jy = rng.integers(-jitter, jitter + 1, 2)
+                        fr[0][ty:ty + 64, tx:tx + 64] = planes[0][oy + jy + ty:oy + jy + ty + 64, ox + jx + tx:ox + jx + tx + 64][:h - ty, :w - tx]
+            if i > 0 and rng.uniform() < patch_prob:
+                ps = min(256, h // 3)
+                py, px = int(rng.integers(0, h - ps)), int(rng.integers(0, w - ps))
+                fr[0][py:py + ps, px:px + ps] = rng.uniform(0.0, 1.0, (ps, ps))
+            for p in fr:
+                f.write(np.clip(np.round(p * mx), 0, mx).astype(dt).tobytes())
+
+
+def run(cmd, **kw):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, **kw)
+    if r.returncode:
+        sys.exit(f"FAILED ({r.returncode}): {' '.join(cmd)}\n{r.stdout.decode(errors='replace')[-2000:]}")
+    return r.stdout.decode(errors="replace")
+
+
+def md5_list(decoder, ivf):
+    out = run([decoder, "--i420" if False else "--rawvideo", "--md5", "-o", "img-%wx%h-%4.i420", ivf])
+    return [l for l in out.splitlines() if re.match(r"^[0-9a-f]{32}  img-", l)]
+
+
+def make(name):
+    w, h, n, seed, dx, dy, bits, chroma, patch, jitter, enc, big = STREAMS[name]
+    outdir = BIG if big else HERE
+    os.makedirs(outdir, exist_ok=True)
+    ivf = os.path.join(outdir, name + ".ivf")
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "src.yuv")
+        source(yuv, w, h, n, seed, dx, dy, bits, chroma, patch, jitter)
+        fmt = ["--i420"] if chroma == "420" else ["--i444"]
+        run([os.path.join(VPX, "vpxenc_c")] + COMMON + fmt + enc + ["-w", str(w), "-h", str(h), f"--limit={n}",
+             f"--fpf={tmp}/fpf", "-o", ivf, yuv])
+    lines = md5_list(os.path.join(VPX, "vpxdec_c"), ivf)
+    if len(lines) < n - 1:
+        sys.exit(f"{name}: only {len(lines)} frames decoded")
+    if bits > 8 and w % 64 == 0 and h % 64 == 0:  # the unchanged reference driver agrees with the patched one
+        if md5_list(os.path.join(VPX, "vpxdec_cA"), ivf) != lines:
+            sys.exit(f"{name}: unchanged and patched reference drivers disagree")
+    with open(os.path.join(outdir, name + ".md5"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print(f"{name}: {os.path.getsize(ivf)} bytes, {len(lines)} frames, list md5 {hashlib.md5(''.join(lines).encode()).hexdigest()[:8]}")
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    names = args or [k for k, v in STREAMS.items() if v[-1] == ("--big" in sys.argv)]
+    for nm in names:
+        make(nm)
