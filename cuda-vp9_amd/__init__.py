@@ -164,6 +164,13 @@ class Decoder:
         L.vp9hip_decoder_alloc_slot.argtypes = [vp] + [ctypes.c_int] * 7
         L.vp9hip_decoder_begin_frame.argtypes = [vp, ctypes.POINTER(FrameParams), vp, ctypes.c_int,
                                                  ctypes.POINTER(CoeffLayout), ctypes.POINTER(vp * 3)]
+        L.vp9hip_decoder_begin_frame_ex.argtypes = L.vp9hip_decoder_begin_frame.argtypes + [ctypes.c_int]
+        L.vp9hip_decoder_current_set.argtypes = [vp]
+        L.vp9hip_decoder_select_set.argtypes = [vp, ctypes.c_int]
+        L.vp9hip_decoder_host_alloc.argtypes = [vp, ctypes.c_size_t]
+        L.vp9hip_decoder_host_alloc.restype = vp
+        L.vp9hip_decoder_host_free.argtypes = [vp, vp]
+        L.vp9hip_decoder_host_free.restype = None
         L.vp9hip_decoder_run.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int * 3), ctypes.c_int, vp, vp]
         L.vp9hip_decoder_sync.argtypes = [vp]
         L.vp9hip_decoder_last_run_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -197,7 +204,20 @@ class Decoder:
         self.check(lib().vp9hip_decoder_alloc_slot(self.handle, slot, width, height, 1, bit_depth, int(bit_depth > 8),
                                                    int(clear)))
 
-    def begin_frame(self, params, blocks, eob_planes=None, coef_planes=None):
+    def host_array(self, n, dtype):
+        """A page-locked numpy array (vp9hip_decoder_host_alloc); freed with the decoder."""
+        nbytes = max(1, int(n)) * np.dtype(dtype).itemsize
+        p = lib().vp9hip_decoder_host_alloc(self.handle, nbytes)
+        if not p:
+            raise Vp9HipError("vp9hip_decoder_host_alloc failed")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return np.frombuffer((ctypes.c_char * nbytes).from_address(p), dtype=dtype, count=int(n))
+
+    def begin_frame(self, params, blocks, eob_planes=None, coef_planes=None, persistent=False):
+        """persistent: coef_planes are page-locked arrays (host_array) left alone until the frame was run
+        and synchronised: nothing is copied synchronously (VP9HIP_BEGIN_HOST_PERSISTENT).  Returns the
+        ring set the frame went to."""
         blocks = np.ascontiguousarray(blocks, BLOCK_DTYPE)
         self._keep = [blocks]
         cl, dq = None, None
@@ -211,9 +231,13 @@ class Decoder:
             arrs = [np.ascontiguousarray(c, np.int32) for c in coef_planes]
             self._keep += arrs
             dq = (ctypes.c_void_p * 3)(*[a.ctypes.data if len(a) else None for a in arrs])
-        self.check(lib().vp9hip_decoder_begin_frame(self.handle, ctypes.byref(params), blocks.ctypes.data, len(blocks),
-                                                    ctypes.byref(cl) if cl is not None else None,
-                                                    ctypes.byref(dq) if dq is not None else None))
+        self.check(lib().vp9hip_decoder_begin_frame_ex(self.handle, ctypes.byref(params), blocks.ctypes.data, len(blocks),
+                                                       ctypes.byref(cl) if cl is not None else None,
+                                                       ctypes.byref(dq) if dq is not None else None, int(bool(persistent))))
+        return lib().vp9hip_decoder_current_set(self.handle)
+
+    def select_set(self, ring_set):
+        self.check(lib().vp9hip_decoder_select_set(self.handle, ring_set))
 
     def run(self, phases, ref_slots, dst_slot, lfm=None, thresh=None):
         rs = (ctypes.c_int * 3)(*ref_slots)
@@ -231,6 +255,9 @@ class Decoder:
 
     def close(self):
         if self.handle:
+            for p in getattr(self, "_pinned", []):
+                lib().vp9hip_decoder_host_free(self.handle, p)
+            self._pinned = []
             lib().vp9hip_decoder_destroy(self.handle)
             self.handle = None
 

@@ -22,21 +22,31 @@ struct Slot {
 
 }  // namespace
 
-struct vp9hip_decoder {
-  vp9hip_ctx *ctx;
+// One set of work lists: the packer that builds them (its arrays are page-locked host memory), their
+// device copies, and two events — `uploaded` (copy stream: lists + coefficients are in HBM) and `done`
+// (launch stream: the kernels that read them have finished).  The decoder owns a RING of sets (SURVEY
+// §8f-1): frame N+1 is packed and uploaded while the kernels of frame N run.
+struct ListSet {
   vp9hip_packer *pk;
-  char err[512];
-  Slot slots[VP9HIP_POOL_SLOTS];
-  DevVec d_inter, d_txb, d_isl_tasks, d_islands, d_wave_off, d_big_tasks, d_lfm, d_coeffs, d_res[3], d_sb_expected;
-  int32_t res_stride[3];
-  bool have_res;
-  bool begun;
-  bool have_coeffs;
+  DevVec d_inter, d_txb, d_isl_tasks, d_islands, d_wave_off, d_big_tasks, d_lfm, d_coeffs, d_sb_expected;
   vp9hip_frame_params params;
   vp9hip_packed packed;
-  int32_t *big_wave_start;  // host copy (the packer's array is reused by the next frame)
+  int32_t *big_wave_start;  // host copy (read at launch time)
   size_t big_wave_cap;
+  hipEvent_t uploaded, done;
+  bool begun, have_coeffs, done_pending;
+};
 
+struct vp9hip_decoder {
+  vp9hip_ctx *ctx;
+  hipStream_t copy_stream;
+  char err[512];
+  Slot slots[VP9HIP_POOL_SLOTS];
+  ListSet sets[VP9HIP_RING_SETS];
+  int cur, next;
+  DevVec d_res[3];
+  int32_t res_stride[3];
+  bool have_res;
   bool timed;
 };
 
@@ -74,11 +84,25 @@ static int dv_reserve(vp9hip_decoder *dec, DevVec *v, size_t bytes) {
   return VP9HIP_OK;
 }
 
-static int dv_upload(vp9hip_decoder *dec, DevVec *v, const void *src, size_t bytes) {
+static int dv_upload_on(vp9hip_decoder *dec, DevVec *v, const void *src, size_t bytes, hipStream_t st) {
   int rc = dv_reserve(dec, v, bytes ? bytes : 16);
   if (rc) return rc;
-  if (bytes) DEC_HIP(dec, hipMemcpyAsync(v->p, src, bytes, hipMemcpyHostToDevice, dec->ctx->stream));
+  if (bytes) DEC_HIP(dec, hipMemcpyAsync(v->p, src, bytes, hipMemcpyHostToDevice, st));
   return VP9HIP_OK;
+}
+
+static int dv_upload(vp9hip_decoder *dec, DevVec *v, const void *src, size_t bytes) {
+  return dv_upload_on(dec, v, src, bytes, dec->ctx->stream);
+}
+
+static void *pinned_alloc(void *user, size_t bytes) {
+  (void)user;
+  void *p = NULL;
+  return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : NULL;
+}
+static void pinned_free(void *user, void *p) {
+  (void)user;
+  (void)hipHostFree(p);
 }
 
 extern "C" int vp9hip_decoder_create(int device, vp9hip_decoder **out) {
@@ -91,11 +115,16 @@ extern "C" int vp9hip_decoder_create(int device, vp9hip_decoder **out) {
     free(dec);
     return rc;  // text in vp9hip_last_error(NULL)
   }
-  rc = vp9hip_packer_create(&dec->pk);
-  if (rc) {
-    vp9hip_destroy(dec->ctx);
-    free(dec);
-    return rc;
+  bool ok = hipStreamCreateWithFlags(&dec->copy_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < VP9HIP_RING_SETS && ok; ++i) {
+    ListSet *s = &dec->sets[i];
+    ok = vp9hip_packer_create_ex(&s->pk, pinned_alloc, pinned_free, NULL) == VP9HIP_OK &&
+         hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&s->done, hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) {
+    vp9hip_decoder_destroy(dec);
+    return VP9HIP_ENOMEM;
   }
   *out = dec;
   return VP9HIP_OK;
@@ -105,17 +134,35 @@ extern "C" void vp9hip_decoder_destroy(vp9hip_decoder *dec) {
   if (!dec) return;
   (void)hipSetDevice(dec->ctx->device);
   (void)hipStreamSynchronize(dec->ctx->stream);
+  if (dec->copy_stream) (void)hipStreamSynchronize(dec->copy_stream);
   for (int s = 0; s < VP9HIP_POOL_SLOTS; ++s)
     for (int p = 0; p < 3; ++p)
       if (dec->slots[s].f.plane[p]) (void)hipFree(dec->slots[s].f.plane[p]);
-  DevVec *all[] = { &dec->d_inter, &dec->d_txb, &dec->d_isl_tasks, &dec->d_islands, &dec->d_wave_off, &dec->d_big_tasks,
-                    &dec->d_lfm,   &dec->d_coeffs, &dec->d_res[0], &dec->d_res[1], &dec->d_res[2], &dec->d_sb_expected };
-  for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i)
-    if (all[i]->p) (void)hipFree(all[i]->p);
-  free(dec->big_wave_start);
-  vp9hip_packer_destroy(dec->pk);
+  for (int i = 0; i < VP9HIP_RING_SETS; ++i) {
+    ListSet *s = &dec->sets[i];
+    DevVec *all[] = { &s->d_inter, &s->d_txb, &s->d_isl_tasks, &s->d_islands, &s->d_wave_off, &s->d_big_tasks,
+                      &s->d_lfm,   &s->d_coeffs, &s->d_sb_expected };
+    for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); ++k)
+      if (all[k]->p) (void)hipFree(all[k]->p);
+    free(s->big_wave_start);
+    if (s->pk) vp9hip_packer_destroy(s->pk);
+    if (s->uploaded) (void)hipEventDestroy(s->uploaded);
+    if (s->done) (void)hipEventDestroy(s->done);
+  }
+  for (int p = 0; p < 3; ++p)
+    if (dec->d_res[p].p) (void)hipFree(dec->d_res[p].p);
+  if (dec->copy_stream) (void)hipStreamDestroy(dec->copy_stream);
   vp9hip_destroy(dec->ctx);
   free(dec);
+}
+
+extern "C" void *vp9hip_decoder_host_alloc(vp9hip_decoder *dec, size_t bytes) {
+  if (!dec || hipSetDevice(dec->ctx->device) != hipSuccess) return NULL;
+  return pinned_alloc(NULL, bytes);
+}
+
+extern "C" void vp9hip_decoder_host_free(vp9hip_decoder *dec, void *p) {
+  if (dec && p) pinned_free(NULL, p);
 }
 
 extern "C" const char *vp9hip_decoder_error(const vp9hip_decoder *dec) {
@@ -222,55 +269,85 @@ extern "C" int vp9hip_decoder_slot_frame(vp9hip_decoder *dec, int slot, vp9hip_f
   return VP9HIP_OK;
 }
 
-extern "C" int vp9hip_decoder_begin_frame(vp9hip_decoder *dec, const vp9hip_frame_params *params,
-                                          const vp9hip_block *blocks, int n_blocks, const vp9hip_coeff_layout *layout,
-                                          const int32_t *const dqcoeff[3]) {
+extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_frame_params *params,
+                                             const vp9hip_block *blocks, int n_blocks, const vp9hip_coeff_layout *layout,
+                                             const int32_t *const dqcoeff[3], int flags) {
   if (!dec) return VP9HIP_EINVAL;
   if (!params) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: null params");
   if (dqcoeff && !layout) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: dqcoeff without the eob layout");
-  dec->begun = false;
-  dec->have_res = false;
   DEC_HIP(dec, hipSetDevice(dec->ctx->device));
-  // the packer's arrays may still be the source of an in-flight copy of the previous frame
-  DEC_HIP(dec, hipStreamSynchronize(dec->ctx->stream));
-  int rc = vp9hip_pack_frame(dec->pk, params, blocks, n_blocks, layout, &dec->packed);
-  if (rc) DEC_FAIL(dec, rc, "%s", vp9hip_packer_error(dec->pk));
-  const vp9hip_packed *P = &dec->packed;
-  dec->params = *params;
-  if ((rc = dv_upload(dec, &dec->d_inter, P->inter, sizeof(vp9hip_inter_task) * (size_t)P->n_inter))) return rc;
-  if ((rc = dv_upload(dec, &dec->d_txb, P->txb, sizeof(vp9hip_txb) * (size_t)P->n_txb))) return rc;
-  if ((rc = dv_upload(dec, &dec->d_isl_tasks, P->intra_island_tasks, sizeof(vp9hip_intra_task) * (size_t)P->n_intra_island_tasks)))
+  ListSet *S = &dec->sets[dec->next];
+  dec->cur = dec->next;
+  dec->next = (dec->next + 1) % VP9HIP_RING_SETS;
+  S->begun = false;
+  dec->have_res = false;
+  // this set's previous frame: its kernels must be through with the device lists, and (earlier on the
+  // timeline) its copies with the packer's page-locked arrays, before either is overwritten
+  if (S->done_pending) {
+    DEC_HIP(dec, hipEventSynchronize(S->done));
+    S->done_pending = false;
+  } else {
+    DEC_HIP(dec, hipEventSynchronize(S->uploaded));  // begun but never run
+  }
+  int rc = vp9hip_pack_frame(S->pk, params, blocks, n_blocks, layout, &S->packed);
+  if (rc) DEC_FAIL(dec, rc, "%s", vp9hip_packer_error(S->pk));
+  const vp9hip_packed *P = &S->packed;
+  const hipStream_t cs = dec->copy_stream;
+  S->params = *params;
+  if ((rc = dv_upload_on(dec, &S->d_inter, P->inter, sizeof(vp9hip_inter_task) * (size_t)P->n_inter, cs))) return rc;
+  if ((rc = dv_upload_on(dec, &S->d_txb, P->txb, sizeof(vp9hip_txb) * (size_t)P->n_txb, cs))) return rc;
+  if ((rc = dv_upload_on(dec, &S->d_isl_tasks, P->intra_island_tasks, sizeof(vp9hip_intra_task) * (size_t)P->n_intra_island_tasks, cs)))
     return rc;
-  if ((rc = dv_upload(dec, &dec->d_islands, P->islands, sizeof(vp9hip_intra_island) * (size_t)P->n_islands))) return rc;
-  if ((rc = dv_upload(dec, &dec->d_wave_off, P->island_wave_off, sizeof(int32_t) * (size_t)P->n_island_wave_off))) return rc;
-  if ((rc = dv_upload(dec, &dec->d_big_tasks, P->intra_big_tasks, sizeof(vp9hip_intra_task) * (size_t)P->n_intra_big_tasks)))
+  if ((rc = dv_upload_on(dec, &S->d_islands, P->islands, sizeof(vp9hip_intra_island) * (size_t)P->n_islands, cs))) return rc;
+  if ((rc = dv_upload_on(dec, &S->d_wave_off, P->island_wave_off, sizeof(int32_t) * (size_t)P->n_island_wave_off, cs))) return rc;
+  if ((rc = dv_upload_on(dec, &S->d_big_tasks, P->intra_big_tasks, sizeof(vp9hip_intra_task) * (size_t)P->n_intra_big_tasks, cs)))
     return rc;
-  if (P->lfm && (rc = dv_upload(dec, &dec->d_lfm, P->lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols))) return rc;
-  if ((size_t)(P->n_big_waves + 1) > dec->big_wave_cap) {
-    free(dec->big_wave_start);
-    dec->big_wave_cap = (size_t)P->n_big_waves + 64;
-    dec->big_wave_start = (int32_t *)malloc(sizeof(int32_t) * dec->big_wave_cap);
-    if (!dec->big_wave_start) {
-      dec->big_wave_cap = 0;
+  if (P->lfm && (rc = dv_upload_on(dec, &S->d_lfm, P->lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols, cs))) return rc;
+  if ((size_t)(P->n_big_waves + 1) > S->big_wave_cap) {
+    free(S->big_wave_start);
+    S->big_wave_cap = (size_t)P->n_big_waves + 64;
+    S->big_wave_start = (int32_t *)malloc(sizeof(int32_t) * S->big_wave_cap);
+    if (!S->big_wave_start) {
+      S->big_wave_cap = 0;
       DEC_FAIL(dec, VP9HIP_ENOMEM, "out of host memory");
     }
   }
-  memcpy(dec->big_wave_start, P->big_wave_start, sizeof(int32_t) * (size_t)(P->n_big_waves + 1));
+  memcpy(S->big_wave_start, P->big_wave_start, sizeof(int32_t) * (size_t)(P->n_big_waves + 1));
   if (P->island_sb_expected &&
-      (rc = dv_upload(dec, &dec->d_sb_expected, P->island_sb_expected, sizeof(int32_t) * (size_t)P->sb_rows * P->sb_cols)))
+      (rc = dv_upload_on(dec, &S->d_sb_expected, P->island_sb_expected, sizeof(int32_t) * (size_t)P->sb_rows * P->sb_cols, cs)))
     return rc;
-  if ((rc = dv_reserve(dec, &dec->d_coeffs, sizeof(int32_t) * (size_t)(P->coeff_total + 16)))) return rc;
-  dec->have_coeffs = dqcoeff != NULL;
+  if ((rc = dv_reserve(dec, &S->d_coeffs, sizeof(int32_t) * (size_t)(P->coeff_total + 16)))) return rc;
+  S->have_coeffs = dqcoeff != NULL;
   if (dqcoeff)
     for (int p = 0; p < 3; ++p)
       if (P->coeff_count[p]) {
         if (!dqcoeff[p]) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: dqcoeff[%d] is null", p);
-        DEC_HIP(dec, hipMemcpyAsync((int32_t *)dec->d_coeffs.p + P->coeff_base[p], dqcoeff[p],
-                                    sizeof(int32_t) * (size_t)P->coeff_count[p], hipMemcpyHostToDevice, dec->ctx->stream));
+        DEC_HIP(dec, hipMemcpyAsync((int32_t *)S->d_coeffs.p + P->coeff_base[p], dqcoeff[p],
+                                    sizeof(int32_t) * (size_t)P->coeff_count[p], hipMemcpyHostToDevice, cs));
       }
-  // the host arrays (packer's, caller's) may be reused as soon as this returns
-  DEC_HIP(dec, hipStreamSynchronize(dec->ctx->stream));
-  dec->begun = true;
+  DEC_HIP(dec, hipEventRecord(S->uploaded, cs));
+  // a caller that may reuse its coefficient arrays right away (the reference frees them at the end of
+  // decode_tiles) gets the synchronous contract; page-locked arrays that live until the frame has been
+  // run (VP9HIP_BEGIN_HOST_PERSISTENT) travel while the caller goes on
+  if (dqcoeff && !(flags & VP9HIP_BEGIN_HOST_PERSISTENT)) DEC_HIP(dec, hipEventSynchronize(S->uploaded));
+  S->begun = true;
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_decoder_begin_frame(vp9hip_decoder *dec, const vp9hip_frame_params *params,
+                                          const vp9hip_block *blocks, int n_blocks, const vp9hip_coeff_layout *layout,
+                                          const int32_t *const dqcoeff[3]) {
+  return vp9hip_decoder_begin_frame_ex(dec, params, blocks, n_blocks, layout, dqcoeff, 0);
+}
+
+extern "C" int vp9hip_decoder_current_set(const vp9hip_decoder *dec) { return dec ? dec->cur : -1; }
+
+extern "C" int vp9hip_decoder_select_set(vp9hip_decoder *dec, int set) {
+  if (!dec) return VP9HIP_EINVAL;
+  if (set < 0 || set >= VP9HIP_RING_SETS || !dec->sets[set].begun)
+    DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_select_set: set %d holds no frame", set);
+  dec->cur = set;
+  dec->have_res = false;
   return VP9HIP_OK;
 }
 
@@ -328,14 +405,15 @@ __global__ void mark_identity_kernel(vp9hip_intra_task *tasks, int n) {
 extern "C" int vp9hip_decoder_set_residual_planes(vp9hip_decoder *dec, const int64_t *const res[3],
                                                   const int32_t stride[3]) {
   if (!dec) return VP9HIP_EINVAL;
-  if (!dec->begun) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_set_residual_planes: no frame begun");
+  ListSet *S = &dec->sets[dec->cur];
+  if (!S->begun) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_set_residual_planes: no frame begun");
   if (!res || !stride || !res[0] || !res[1] || !res[2]) DEC_FAIL(dec, VP9HIP_EINVAL, "null residual plane");
-  if (!dec->params.hbd)
+  if (!S->params.hbd)
     DEC_FAIL(dec, VP9HIP_EINVAL,
              "residual-plane mode needs a high-bitdepth frame (the reference's CPU transforms only produce int64 "
              "residuals on their highbd path); pass the coefficient buffers to vp9hip_decoder_begin_frame instead");
-  if (dec->have_coeffs) DEC_FAIL(dec, VP9HIP_EINVAL, "coefficients were already given for this frame");
-  const int aw = (dec->params.width + 7) & ~7, ah = (dec->params.height + 7) & ~7, ss = dec->params.ss_x;
+  if (S->have_coeffs) DEC_FAIL(dec, VP9HIP_EINVAL, "coefficients were already given for this frame");
+  const int aw = (S->params.width + 7) & ~7, ah = (S->params.height + 7) & ~7, ss = S->params.ss_x;
   DEC_HIP(dec, hipSetDevice(dec->ctx->device));
   for (int p = 0; p < 3; ++p) {
     const int w = p ? aw >> ss : aw, h = p ? ah >> ss : ah;
@@ -354,24 +432,26 @@ extern "C" int vp9hip_decoder_set_residual_planes(vp9hip_decoder *dec, const int
 extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref_slot[3], int dst_slot,
                                   const vp9hip_lfm *h_lfm, const vp9hip_lf_thresh *thresh) {
   if (!dec) return VP9HIP_EINVAL;
-  if (!dec->begun) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: no frame begun");
+  ListSet *S = &dec->sets[dec->cur];
+  if (!S->begun) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: no frame begun");
   if (dst_slot < 0 || dst_slot >= VP9HIP_POOL_SLOTS || !dec->slots[dst_slot].used)
     DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: destination slot %d holds no frame", dst_slot);
-  const vp9hip_packed *P = &dec->packed;
+  const vp9hip_packed *P = &S->packed;
   const vp9hip_frame *dst = &dec->slots[dst_slot].f;
-  if (dst->width[0] != dec->params.width || dst->height[0] != dec->params.height || dst->hbd != (dec->params.hbd ? 1 : 0) ||
-      dst->bit_depth != dec->params.bit_depth)
+  if (dst->width[0] != S->params.width || dst->height[0] != S->params.height || dst->hbd != (S->params.hbd ? 1 : 0) ||
+      dst->bit_depth != S->params.bit_depth)
     DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: destination slot geometry differs from the frame parameters");
   DEC_HIP(dec, hipSetDevice(dec->ctx->device));
   hipStream_t st = dec->ctx->stream;
+  DEC_HIP(dec, hipStreamWaitEvent(st, S->uploaded, 0));
   DEC_CTX(dec, vp9hip_timer_begin(dec->ctx, TIMER_RUN));
 
   // coefficient mode: the island tasks' inverse transforms only need the coefficients — they start beside
   // the convolve and the inter transforms (in residual-plane mode the residual is gathered later)
-  if ((phases & VP9HIP_PHASE_INTER) && (phases & VP9HIP_PHASE_INTRA) && P->n_islands && dec->have_coeffs && !dec->have_res)
-    DEC_CTX(dec, vp9hip_intra_residual_begin(dec->ctx, (const vp9hip_intra_task *)dec->d_isl_tasks.p,
-                                             (const vp9hip_intra_island *)dec->d_islands.p, P->n_islands,
-                                             (const int32_t *)dec->d_wave_off.p, (const int32_t *)dec->d_coeffs.p, dst));
+  if ((phases & VP9HIP_PHASE_INTER) && (phases & VP9HIP_PHASE_INTRA) && P->n_islands && S->have_coeffs && !dec->have_res)
+    DEC_CTX(dec, vp9hip_intra_residual_begin(dec->ctx, (const vp9hip_intra_task *)S->d_isl_tasks.p,
+                                             (const vp9hip_intra_island *)S->d_islands.p, P->n_islands,
+                                             (const int32_t *)S->d_wave_off.p, (const int32_t *)S->d_coeffs.p, dst));
 
   if ((phases & VP9HIP_PHASE_INTER)) {
     if (P->n_inter) {
@@ -382,9 +462,9 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
         const int s = ref_slot ? ref_slot[k] : -1;
         if (s >= 0 && s < VP9HIP_POOL_SLOTS && dec->slots[s].used) {
           refs[k] = dec->slots[s].f;
-          if (needed && (refs[k].width[0] != dec->params.ref_width[k] || refs[k].height[0] != dec->params.ref_height[k]))
+          if (needed && (refs[k].width[0] != S->params.ref_width[k] || refs[k].height[0] != S->params.ref_height[k]))
             DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: reference %d is %dx%d in the pool, %dx%d in the parameters", k,
-                     refs[k].width[0], refs[k].height[0], dec->params.ref_width[k], dec->params.ref_height[k]);
+                     refs[k].width[0], refs[k].height[0], S->params.ref_width[k], S->params.ref_height[k]);
           if (needed && (refs[k].hbd != dst->hbd || refs[k].bit_depth != dst->bit_depth))
             DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: reference %d has another sample format", k);
         } else if (needed) {
@@ -393,7 +473,7 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
           refs[k] = *dst;  // placeholder, never read
         }
       }
-      DEC_CTX(dec, vp9hip_inter_pred_batch(dec->ctx, (const vp9hip_inter_task *)dec->d_inter.p, P->inter_class_count, refs, 3, dst));
+      DEC_CTX(dec, vp9hip_inter_pred_batch(dec->ctx, (const vp9hip_inter_task *)S->d_inter.p, P->inter_class_count, refs, 3, dst));
     }
     if (dec->have_res) {
       for (int p = 0; p < 3; ++p) {
@@ -403,23 +483,23 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
       }
       DEC_HIP(dec, hipGetLastError());
     } else if (P->n_txb) {
-      if (!dec->have_coeffs) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: the frame has residuals but no coefficients were given");
-      DEC_CTX(dec, vp9hip_idct_add_batch(dec->ctx, (const vp9hip_txb *)dec->d_txb.p, P->txb_size_count, (const int32_t *)dec->d_coeffs.p, dst));
+      if (!S->have_coeffs) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: the frame has residuals but no coefficients were given");
+      DEC_CTX(dec, vp9hip_idct_add_batch(dec->ctx, (const vp9hip_txb *)S->d_txb.p, P->txb_size_count, (const int32_t *)S->d_coeffs.p, dst));
     }
   }
 
   if ((phases & VP9HIP_PHASE_INTRA) && P->n_intra) {
-    const int32_t *coeffs = (dec->have_coeffs || dec->have_res) ? (const int32_t *)dec->d_coeffs.p : NULL;
+    const int32_t *coeffs = (S->have_coeffs || dec->have_res) ? (const int32_t *)S->d_coeffs.p : NULL;
     if (dec->have_res) {
       // residual of coded intra blocks: gather from the planes into the coefficient slots
-      vp9hip_intra_task *lists[2] = { (vp9hip_intra_task *)dec->d_isl_tasks.p, (vp9hip_intra_task *)dec->d_big_tasks.p };
+      vp9hip_intra_task *lists[2] = { (vp9hip_intra_task *)S->d_isl_tasks.p, (vp9hip_intra_task *)S->d_big_tasks.p };
       const int counts[2] = { P->n_intra_island_tasks, P->n_intra_big_tasks };
       for (int l = 0; l < 2; ++l) {
         if (!counts[l]) continue;
         hipLaunchKernelGGL(residual_gather_kernel, dim3(counts[l]), dim3(256), 0, st, lists[l], counts[l],
                            (const int64_t *)dec->d_res[0].p, (const int64_t *)dec->d_res[1].p, (const int64_t *)dec->d_res[2].p,
                            dec->res_stride[0], dec->res_stride[1], dec->res_stride[2], dst->aheight[0], dst->aheight[1],
-                           (int32_t *)dec->d_coeffs.p);
+                           (int32_t *)S->d_coeffs.p);
         hipLaunchKernelGGL(mark_identity_kernel, dim3((counts[l] + 255) / 256), dim3(256), 0, st, lists[l], counts[l]);
       }
       DEC_HIP(dec, hipGetLastError());
@@ -431,23 +511,23 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
                          (h_lfm || P->lfm);
     if (overlap) {
       if (h_lfm) {
-        int rc = dv_upload(dec, &dec->d_lfm, h_lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols);
+        int rc = dv_upload(dec, &S->d_lfm, h_lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols);
         if (rc) return rc;
         DEC_HIP(dec, hipStreamSynchronize(st));
       }
-      DEC_CTX(dec, vp9hip_intra_islands_lf(dec->ctx, (const vp9hip_intra_task *)dec->d_isl_tasks.p,
-                                           (const vp9hip_intra_island *)dec->d_islands.p, P->n_islands,
-                                           (const int32_t *)dec->d_wave_off.p, coeffs, (const int32_t *)dec->d_sb_expected.p,
-                                           (const vp9hip_lfm *)dec->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
-                                           dec->params.ss_x ? 3 : 1));
+      DEC_CTX(dec, vp9hip_intra_islands_lf(dec->ctx, (const vp9hip_intra_task *)S->d_isl_tasks.p,
+                                           (const vp9hip_intra_island *)S->d_islands.p, P->n_islands,
+                                           (const int32_t *)S->d_wave_off.p, coeffs, (const int32_t *)S->d_sb_expected.p,
+                                           (const vp9hip_lfm *)S->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
+                                           S->params.ss_x ? 3 : 1));
       phases &= ~VP9HIP_PHASE_LF;
     } else {
       if (P->n_islands)
-        DEC_CTX(dec, vp9hip_intra_pred_islands(dec->ctx, (const vp9hip_intra_task *)dec->d_isl_tasks.p,
-                                               (const vp9hip_intra_island *)dec->d_islands.p, P->n_islands,
-                                               (const int32_t *)dec->d_wave_off.p, coeffs, dst));
+        DEC_CTX(dec, vp9hip_intra_pred_islands(dec->ctx, (const vp9hip_intra_task *)S->d_isl_tasks.p,
+                                               (const vp9hip_intra_island *)S->d_islands.p, P->n_islands,
+                                               (const int32_t *)S->d_wave_off.p, coeffs, dst));
       if (P->n_intra_big_tasks)
-        DEC_CTX(dec, vp9hip_intra_pred_waves(dec->ctx, (const vp9hip_intra_task *)dec->d_big_tasks.p, dec->big_wave_start,
+        DEC_CTX(dec, vp9hip_intra_pred_waves(dec->ctx, (const vp9hip_intra_task *)S->d_big_tasks.p, S->big_wave_start,
                                              P->n_big_waves, coeffs, dst));
     }
   }
@@ -455,16 +535,18 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
   if (phases & VP9HIP_PHASE_LF) {
     if (!thresh) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: loop filter needs the threshold table");
     if (h_lfm) {
-      int rc = dv_upload(dec, &dec->d_lfm, h_lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols);
+      int rc = dv_upload(dec, &S->d_lfm, h_lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols);
       if (rc) return rc;
       DEC_HIP(dec, hipStreamSynchronize(st));  // h_lfm may be pageable and change after we return
     } else if (!P->lfm) {
       DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: no loop-filter masks (set params.build_lf_masks or pass them)");
     }
-    DEC_CTX(dec, vp9hip_loop_filter_frame(dec->ctx, (const vp9hip_lfm *)dec->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
-                                          dec->params.ss_x ? 3 : 1));
+    DEC_CTX(dec, vp9hip_loop_filter_frame(dec->ctx, (const vp9hip_lfm *)S->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
+                                          S->params.ss_x ? 3 : 1));
   }
   DEC_CTX(dec, vp9hip_timer_end(dec->ctx, TIMER_RUN));
+  DEC_HIP(dec, hipEventRecord(S->done, st));
+  S->done_pending = true;
   dec->timed = true;
   return VP9HIP_OK;
 }
@@ -483,5 +565,5 @@ extern "C" int vp9hip_decoder_last_run_ms(vp9hip_decoder *dec, float *ms) {
 }
 
 extern "C" const vp9hip_packed *vp9hip_decoder_packed(const vp9hip_decoder *dec) {
-  return dec && dec->begun ? &dec->packed : NULL;
+  return dec && dec->sets[dec->cur].begun ? &dec->sets[dec->cur].packed : NULL;
 }

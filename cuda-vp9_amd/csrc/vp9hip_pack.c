@@ -25,28 +25,49 @@ typedef struct {
 
 struct vp9hip_packer {
   char err[256];
+  vp9hip_alloc_fn alloc;
+  vp9hip_free_fn release;
+  void *alloc_user;
   vec inter, inter_sorted, txb, txb_sorted, intra, intra_isl, intra_big, islands, wave_off, big_wave_start;
   vec level, parent, comp_id, comp_size, order_a, order_b, count;
   vec lvl_map[3], own_map[3];
-  vec lfm, lf_raw, rows_expected;
+  vec lfm, lf_raw, rows_expected, lf_skip;
 };
 
-static int vec_reserve(vec *v, size_t bytes) {
+/* Contents are kept when a vector grows (some are appended to across passes). */
+static int vec_reserve_pk(vp9hip_packer *pk, vec *v, size_t bytes) {
   if (bytes <= v->cap) return 0;
   size_t ncap = v->cap ? v->cap : 4096;
   while (ncap < bytes) ncap *= 2;
-  void *np = realloc(v->p, ncap);
-  if (!np) return -1;
+  void *np;
+  if (pk->alloc) {
+    np = pk->alloc(pk->alloc_user, ncap);
+    if (!np) return -1;
+    if (v->p) {
+      memcpy(np, v->p, v->cap);
+      pk->release(pk->alloc_user, v->p);
+    }
+  } else {
+    np = realloc(v->p, ncap);
+    if (!np) return -1;
+  }
   v->p = np;
   v->cap = ncap;
   return 0;
 }
+#define vec_reserve(v, bytes) vec_reserve_pk(pk, (v), (bytes))
 
-int vp9hip_packer_create(vp9hip_packer **out) {
-  if (!out) return VP9HIP_EINVAL;
+int vp9hip_packer_create_ex(vp9hip_packer **out, vp9hip_alloc_fn alloc, vp9hip_free_fn release, void *user) {
+  if (!out || (alloc != NULL) != (release != NULL)) return VP9HIP_EINVAL;
   *out = (vp9hip_packer *)calloc(1, sizeof(vp9hip_packer));
-  return *out ? VP9HIP_OK : VP9HIP_ENOMEM;
+  if (!*out) return VP9HIP_ENOMEM;
+  (*out)->alloc = alloc;
+  (*out)->release = release;
+  (*out)->alloc_user = user;
+  return VP9HIP_OK;
 }
+
+int vp9hip_packer_create(vp9hip_packer **out) { return vp9hip_packer_create_ex(out, NULL, NULL, NULL); }
 
 void vp9hip_packer_destroy(vp9hip_packer *pk) {
   if (!pk) return;
@@ -54,8 +75,12 @@ void vp9hip_packer_destroy(vp9hip_packer *pk) {
                  &pk->intra_big, &pk->islands,     &pk->wave_off,  &pk->big_wave_start, &pk->level, &pk->parent,
                  &pk->comp_id,  &pk->comp_size,    &pk->order_a,   &pk->order_b,    &pk->count,    &pk->lvl_map[0],
                  &pk->lvl_map[1], &pk->lvl_map[2], &pk->own_map[0], &pk->own_map[1], &pk->own_map[2], &pk->lfm,
-                 &pk->lf_raw,   &pk->rows_expected };
-  for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) free(all[i]->p);
+                 &pk->lf_raw,   &pk->rows_expected, &pk->lf_skip };
+  for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) {
+    if (!all[i]->p) continue;
+    if (pk->release) pk->release(pk->alloc_user, all[i]->p);
+    else free(all[i]->p);
+  }
   free(pk);
 }
 
@@ -132,7 +157,7 @@ typedef struct {
 
 /* vp9_build_mask (vp9/common/vp9_loopfilter.c:1528-1608); the prediction/size masks are the
  * rectangles its tables spell out (:80-195). */
-static void lf_build_mask(lfm_raw *lfm, const vp9hip_block *b) {
+static void lf_build_mask(lfm_raw *lfm, const vp9hip_block *b, int skip) {
   const int level = b->filter_level;
   if (!level) return;
   const int w8 = kW4[b->sb_type] > 1 ? kW4[b->sb_type] >> 1 : 1;
@@ -161,7 +186,7 @@ static void lf_build_mask(lfm_raw *lfm, const vp9hip_block *b) {
     lfm->above_uv[txuv] |= (uint16_t)(above_pred_uv << shift_uv);
     lfm->left_uv[txuv] |= (uint16_t)(left_pred_uv << shift_uv);
   }
-  if (b->skip && b->ref_frame[0] > 0) return;
+  if (skip && b->ref_frame[0] > 0) return;
   {
     /* above_64x64_txform_mask / left_64x64_txform_mask (:39-78): rows / columns at multiples of the
      * transform size */
@@ -413,8 +438,13 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
       vec_reserve(&pk->inter_sorted, (n_inter + 1) * sizeof(vp9hip_inter_task)) ||
       vec_reserve(&pk->txb, (n_tx + 1) * sizeof(vp9hip_txb)) || vec_reserve(&pk->txb_sorted, (n_tx + 1) * sizeof(vp9hip_txb)) ||
       vec_reserve(&pk->intra, (n_tx + 1) * sizeof(vp9hip_intra_task)) ||
-      vec_reserve(&pk->order_a, (n_tx + n_inter + 1) * sizeof(int32_t)))
+      vec_reserve(&pk->order_a, (n_tx + n_inter + 1) * sizeof(int32_t)) || vec_reserve(&pk->lf_skip, (size_t)n_blocks + 1))
     PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+  /* the skip flag the loop filter sees: libvpx turns an inter block of 8x8 or more whose transform blocks
+   * all have eob 0 into a skipped one before the masks are built (`if (!less8x8 && eobtotal == 0)
+   * mi->skip = 1`, vp9/decoder/vp9_decodeframe.c:1195; stock libvpx builds the masks after it) */
+  uint8_t *lf_skip = (uint8_t *)pk->lf_skip.p;
+  const int have_eobs = coeffs && coeffs->eob[0];
   vp9hip_inter_task *it = (vp9hip_inter_task *)pk->inter.p;
   vp9hip_txb *tb = (vp9hip_txb *)pk->txb.p;
   vp9hip_intra_task *ia = (vp9hip_intra_task *)pk->intra.p;
@@ -507,6 +537,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
     }
 
     /* transform blocks: vp9_foreach_transformed_block_in_plane order, clipped to the frame */
+    int eobtotal = 0;
     for (int p = 0; p < 3; ++p) {
       const int s = p ? ss : 0;
       const int n4w = (bw8 * 2) >> s ? (bw8 * 2) >> s : 1, n4h = (bh8 * 2) >> s ? (bh8 * 2) >> s : 1;
@@ -527,6 +558,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
             else if (P->assume_coded)
               eob = 1;
             if (eob < 0 || eob > nn) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: bad eob %d (block %d plane %d)", eob, i, p);
+            eobtotal += eob;
           }
           if (inter) {
             if (eob > 0) {
@@ -559,6 +591,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
           }
         }
     }
+    lf_skip[i] = (uint8_t)(b->skip || (have_eobs && inter && !sub8 && eobtotal == 0));
   }
   if (run[0] != coeff_count[0] || run[1] != coeff_count[1] || run[2] != coeff_count[2])
     PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: internal coefficient count mismatch");
@@ -808,7 +841,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
     vp9hip_lfm *lfm = (vp9hip_lfm *)pk->lfm.p;
     memset(raw, 0, n_sb * sizeof(lfm_raw));
     for (int i = 0; i < n_blocks; ++i)
-      lf_build_mask(&raw[(size_t)(blocks[i].mi_row >> 3) * sb_cols + (blocks[i].mi_col >> 3)], &blocks[i]);
+      lf_build_mask(&raw[(size_t)(blocks[i].mi_row >> 3) * sb_cols + (blocks[i].mi_col >> 3)], &blocks[i], lf_skip[i]);
     for (int r = 0; r < sb_rows; ++r)
       for (int c = 0; c < sb_cols; ++c)
         lf_adjust_mask(&raw[(size_t)r * sb_cols + c], &lfm[(size_t)r * sb_cols + c], r * 8, c * 8, mi_rows, mi_cols);

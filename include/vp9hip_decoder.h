@@ -27,6 +27,10 @@ extern "C" {
 typedef struct vp9hip_decoder vp9hip_decoder;
 
 #define VP9HIP_POOL_SLOTS 16
+/* Work-list sets in the decoder's ring: begin_frame packs frame N+1 into the next set
+ * (page-locked host arrays) and copies it to the device on a copy stream while the kernels of frame N,
+ * which read another set, run on the launch stream. */
+#define VP9HIP_RING_SETS 4
 
 int vp9hip_decoder_create(int device, vp9hip_decoder **out);
 void vp9hip_decoder_destroy(vp9hip_decoder *dec);
@@ -61,6 +65,20 @@ int vp9hip_decoder_slot_frame(vp9hip_decoder *dec, int slot, vp9hip_frame *out);
  *   dqcoeff[p] must hold packed.coeff_count[p] entries. */
 int vp9hip_decoder_begin_frame(vp9hip_decoder *dec, const vp9hip_frame_params *params, const vp9hip_block *blocks,
                                int n_blocks, const vp9hip_coeff_layout *layout, const int32_t *const dqcoeff[3]);
+
+/* Same, with flags.  VP9HIP_BEGIN_HOST_PERSISTENT: dqcoeff[] point into page-locked memory (e.g.
+ * vp9hip_decoder_host_alloc) that stays untouched until the frame has been run and synchronised — the
+ * coefficient copy is then asynchronous as well and the call returns as soon as the frame is packed. */
+#define VP9HIP_BEGIN_HOST_PERSISTENT 1
+int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_frame_params *params, const vp9hip_block *blocks,
+                                  int n_blocks, const vp9hip_coeff_layout *layout, const int32_t *const dqcoeff[3], int flags);
+/* The ring set begin_frame used last (0..VP9HIP_RING_SETS-1), and making an earlier, still-begun set
+ * current again (replaying resident work lists: benchmarks, tests). */
+int vp9hip_decoder_current_set(const vp9hip_decoder *dec);
+int vp9hip_decoder_select_set(vp9hip_decoder *dec, int set);
+/* Page-locked host memory for buffers the caller fills between frames (coefficients). */
+void *vp9hip_decoder_host_alloc(vp9hip_decoder *dec, size_t bytes);
+void vp9hip_decoder_host_free(vp9hip_decoder *dec, void *p);
 
 /* Residual-plane mode — the reference's contract when its CPU phase B is kept
  * (libvpx/vp9/decoder/vp9_decodeframe.c:2443-2486): the inverse transforms were already run on

@@ -30,10 +30,13 @@ struct frame_buffer; /* frameBuf, vpx-master/buffers_struct.h:9-15 */
 void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_buffer *frameBuffer);
 
 /* Phase E on the GPU and references resident in HBM.  When enabled, the intra wrapper
- * also runs the loop filter — with libvpx's own masks (cm->lf.lfm, as vp9_build_mask left them) and
- * threshold table (cm->lf_info.lfthr) — before it delivers the frame, so the caller must NOT run its
- * CPU loop filter (vp9_decodeframe.c:2585-2620) afterwards; and the frame stays in the device pool
- * under its frame-buffer index, so later frames that reference it need no upload. */
+ * also runs the loop filter before it delivers the frame — masks built from the frame's blocks with
+ * vp9_build_mask / vp9_adjust_mask semantics and the skip flag stock libvpx filters with (an inter
+ * block >= 8x8 without coded coefficients counts as skipped, vp9_decodeframe.c:1195), libvpx's
+ * threshold table (cm->lf_info.lfthr) — so the caller must NOT run its CPU loop filter
+ * (vp9_decodeframe.c:2585-2620) afterwards; and the frame stays in the device pool under its
+ * frame-buffer index, so later frames that reference it need no upload.  Repeating the call with the
+ * same value is free (a caller may issue it for every frame). */
 void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable);
 
 /* Frees the GPU state kept for a decoder instance (call from vp9_decoder_remove). */

@@ -32,6 +32,8 @@
 #ifndef VP9HIP_PACK_H_
 #define VP9HIP_PACK_H_
 
+#include <stddef.h>
+
 #include "vp9hip.h"
 
 #ifdef __cplusplus
@@ -127,6 +129,12 @@ typedef struct vp9hip_packer vp9hip_packer;
 /* A packer owns growable host arrays that are reused from frame to frame (the reference mallocs
  * and frees its lists for every frame, vp9_decodeframe.c:2316-2330, 2625-2634). */
 int vp9hip_packer_create(vp9hip_packer **out);
+/* Same, with the packer's arrays taken from the caller's allocator (both functions or neither): the
+ * frame driver passes page-locked host memory so that the work lists go to the device with
+ * asynchronous copies straight from where the packer wrote them. */
+typedef void *(*vp9hip_alloc_fn)(void *user, size_t bytes);
+typedef void (*vp9hip_free_fn)(void *user, void *ptr);
+int vp9hip_packer_create_ex(vp9hip_packer **out, vp9hip_alloc_fn alloc, vp9hip_free_fn release, void *user);
 void vp9hip_packer_destroy(vp9hip_packer *pk);
 const char *vp9hip_packer_error(const vp9hip_packer *pk);
 

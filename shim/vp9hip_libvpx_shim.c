@@ -67,11 +67,30 @@ typedef struct {
     const uint8_t *alloc;
     int w, h, bd, hbd, valid;
   } resident[VP9HIP_POOL_SLOTS];
-  vp9hip_lfm *lfm_adj;
-  int lfm_cap;
 } shim_state;
 
 static shim_state g_state[SHIM_MAX_DECODERS];
+
+/* VP9HIP_SHIM_TRACE=1: where the time of the two entry points goes, summed over the stream and printed
+ * at exit (seconds of host wall time; "kernels" are waits for the GPU) */
+static struct {
+  int on, frames;
+  double gather, pack_upload, refs, inter_wait, masks, intra_wait, download;
+  double gpu_inter_ms, gpu_intra_ms;
+} g_trace;
+
+static void trace_report(void) {
+  if (!g_trace.frames) return;
+  const double n = g_trace.frames, ms = 1e3 / n;
+  fprintf(stderr,
+          "vp9hip shim: %d frames; per frame: gather blocks %.3f ms, pack + list/coefficient upload %.3f ms, reference "
+          "upload + slot %.3f ms, wait inter kernels %.3f ms (GPU %.3f), masks %.3f ms, wait intra+filter kernels %.3f ms "
+          "(GPU %.3f), frame download %.3f ms; total in the entry points %.3f ms\n",
+          g_trace.frames, g_trace.gather * ms, g_trace.pack_upload * ms, g_trace.refs * ms, g_trace.inter_wait * ms,
+          g_trace.gpu_inter_ms / n, g_trace.masks * ms, g_trace.intra_wait * ms, g_trace.gpu_intra_ms / n, g_trace.download * ms,
+          (g_trace.gather + g_trace.pack_upload + g_trace.refs + g_trace.inter_wait + g_trace.masks + g_trace.intra_wait +
+           g_trace.download) * ms);
+}
 
 static double now_s(void) {
   struct timespec ts;
@@ -92,6 +111,10 @@ static shim_state *state_of(VP9Decoder *pbi, VP9_COMMON *cm) {
   shim_state *s = &g_state[free_i];
   memset(s, 0, sizeof(*s));
   const char *dev = getenv("VP9HIP_DEVICE");
+  if (getenv("VP9HIP_SHIM_TRACE") && !g_trace.on) {
+    g_trace.on = 1;
+    atexit(trace_report);
+  }
   int rc = vp9hip_decoder_create(dev ? atoi(dev) : 0, &s->dec);
   if (rc != VP9HIP_OK) {
     vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: %s", vp9hip_last_error(NULL));
@@ -121,7 +144,6 @@ void vp9hip_shim_release(struct VP9Decoder *pbi) {
     if (g_state[i].pbi == pbi) {
       vp9hip_decoder_destroy(g_state[i].dec);
       free(g_state[i].blocks);
-      free(g_state[i].lfm_adj);
       memset(&g_state[i], 0, sizeof(g_state[i]));
     }
 }
@@ -221,7 +243,7 @@ static int gather_blocks(shim_state *s, VP9_COMMON *cm, const int *size_for_mb, 
 }
 
 static void frame_params(const VP9_COMMON *cm, const VP9Decoder *pbi, const YV12_BUFFER_CONFIG *cur, int coefficient_mode,
-                         vp9hip_frame_params *P) {
+                         int gpu_lf, vp9hip_frame_params *P) {
   memset(P, 0, sizeof(*P));
   P->width = cm->width;
   P->height = cm->height;
@@ -232,6 +254,7 @@ static void frame_params(const VP9_COMMON *cm, const VP9Decoder *pbi, const YV12
   P->lossless = pbi->mb.lossless;
   P->log2_tile_cols = cm->log2_tile_cols;
   P->assume_coded = !coefficient_mode;
+  P->build_lf_masks = gpu_lf && cm->lf.filter_level && !cm->skip_loop_filter;
   if (cm->frame_type != KEY_FRAME && !cm->intra_only)
     for (int k = 0; k < 3; ++k) {
       const YV12_BUFFER_CONFIG *rb = cm->frame_refs[k].buf;
@@ -263,9 +286,11 @@ static int begin_frame(shim_state *s, VP9_COMMON *cm, VP9Decoder *pbi, int *size
                        const tran_high_t *residuals, const frameBuf *fb_for_residuals) {
   const YV12_BUFFER_CONFIG *cur = &cm->buffer_pool->frame_bufs[cm->new_fb_idx].buf;
   vp9hip_frame_params P;
+  const double tg0 = now_s();
   const int n = gather_blocks(s, cm, size_for_mb, MiBuf);
   if (n < 0) return -1;
-  frame_params(cm, pbi, cur, s->attached != NULL, &P);
+  g_trace.gather += now_s() - tg0;
+  frame_params(cm, pbi, cur, s->attached != NULL, s->gpu_lf, &P);
   if (s->attached) {
     vp9hip_coeff_layout L;
     const int32_t *dq[3];
@@ -335,12 +360,13 @@ int wrap_cuda_inter_prediction(int n, double *gpu_copy, double *gpu_run, int *si
   SHIM_CHECK(s, cm, vp9hip_decoder_alloc_slot(s->dec, slot_of_cur(s, cm), cm->width, cm->height, cm->subsampling_x,
                                               (int)cm->bit_depth, (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0, 1));
   const double t1 = now_s();
-  if (getenv("VP9HIP_SHIM_TRACE"))
-    fprintf(stderr, "vp9hip shim: inter wrapper: pack + lists + coefficients %.2f ms, references + frame slot %.2f ms\n",
-            (t_begin - t0) * 1e3, (t1 - t_begin) * 1e3);
   SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, VP9HIP_PHASE_INTER, ref_slot, slot_of_cur(s, cm), NULL, NULL));
   SHIM_CHECK(s, cm, vp9hip_decoder_sync(s->dec));
   SHIM_CHECK(s, cm, vp9hip_decoder_last_run_ms(s->dec, &ms));
+  g_trace.pack_upload += t_begin - t0;
+  g_trace.refs += t1 - t_begin;
+  g_trace.inter_wait += now_s() - t1;
+  g_trace.gpu_inter_ms += ms;
   /* the frame stays on the device: wrap_cuda_intra_prediction runs next on the same frame
    * (vp9_decodeframe.c:2546-2564) and delivers it to the host */
   s->frame_open = 1;
@@ -371,46 +397,30 @@ int wrap_cuda_intra_prediction(double *gpu_copy, double *gpu_run, int *size_for_
                                                 (int)cm->bit_depth, (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0, 1));
   }
   s->frame_open = 0;
-  /* phase E on the GPU (vp9hip_shim_set_gpu_loop_filter): libvpx's own masks, adjusted the way
-   * loop_filter_rows does before filtering a superblock (vp9_loopfilter.c:1440-1468), and its threshold
+  /* phase E on the GPU (vp9hip_shim_set_gpu_loop_filter): the masks were built by the packer from the
+   * blocks (vp9_build_mask + vp9_adjust_mask semantics, with the skip flag libvpx's loop filter sees: an
+   * inter block of 8x8 or more without a coded coefficient counts as skipped, vp9_decodeframe.c:1195 — the
+   * masks cm->lf.lfm holds were accumulated at parse time, before that update); libvpx's threshold
    * table; the island walk and the filter then run side by side */
   int phases = VP9HIP_PHASE_INTRA;
-  const vp9hip_lfm *h_lfm = NULL;
   vp9hip_lf_thresh th;
-  if (s->gpu_lf && cm->lf.filter_level && !cm->skip_loop_filter) {
-    const int sb_rows = (cm->mi_rows + 7) >> 3, sb_cols = (cm->mi_cols + 7) >> 3;
-    if (sizeof(LOOP_FILTER_MASK) != sizeof(vp9hip_lfm)) {
-      vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: LOOP_FILTER_MASK layout differs");
-      return -1;
-    }
-    if (sb_rows * sb_cols > s->lfm_cap) {
-      free(s->lfm_adj);
-      s->lfm_cap = sb_rows * sb_cols;
-      s->lfm_adj = (vp9hip_lfm *)malloc(sizeof(vp9hip_lfm) * (size_t)s->lfm_cap);
-      if (!s->lfm_adj) {
-        s->lfm_cap = 0;
-        vpx_internal_error(&cm->error, VPX_CODEC_MEM_ERROR, "vp9hip shim: out of memory");
-        return -1;
-      }
-    }
-    for (int r = 0; r < sb_rows; ++r)
-      memcpy(&s->lfm_adj[(size_t)r * sb_cols], &cm->lf.lfm[(size_t)r * cm->lf.lfm_stride], sizeof(vp9hip_lfm) * (size_t)sb_cols);
-    if (vp9hip_lf_adjust_masks(s->lfm_adj, sb_rows, sb_cols, cm->mi_rows, cm->mi_cols, s->lfm_adj) != VP9HIP_OK) {
-      vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: bad loop-filter mask geometry");
-      return -1;
-    }
+  const int filter = s->gpu_lf && cm->lf.filter_level && !cm->skip_loop_filter;
+  if (filter) {
     for (int l = 0; l < 64; ++l) {
       th.mblim[l] = cm->lf_info.lfthr[l].mblim[0];
       th.lim[l] = cm->lf_info.lfthr[l].lim[0];
       th.hev_thr[l] = cm->lf_info.lfthr[l].hev_thr[0];
     }
-    h_lfm = s->lfm_adj;
     phases |= VP9HIP_PHASE_LF;
   }
   t_copy += now_s() - t0;
-  SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, phases, ref_slot, slot_of_cur(s, cm), h_lfm, h_lfm ? &th : NULL));
+  g_trace.masks += now_s() - t0;
+  t0 = now_s();
+  SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, phases, ref_slot, slot_of_cur(s, cm), NULL, filter ? &th : NULL));
   SHIM_CHECK(s, cm, vp9hip_decoder_sync(s->dec));
   SHIM_CHECK(s, cm, vp9hip_decoder_last_run_ms(s->dec, &ms));
+  g_trace.intra_wait += now_s() - t0;
+  g_trace.gpu_intra_ms += ms;
   /* the reference's contract: the reconstructed frame is in the host buffer on return, because the
    * CPU loop filter runs next (vp9_decodeframe.c:2585; intra_cuda_kernel.cu:1368).  With the GPU loop
    * filter the delivered frame is already filtered (the caller drops phase E) and the device copy
@@ -420,6 +430,8 @@ int wrap_cuda_intra_prediction(double *gpu_copy, double *gpu_run, int *size_for_
   SHIM_CHECK(s, cm, vp9hip_decoder_download(s->dec, slot_of_cur(s, cm), &h));
   if (s->gpu_lf) mark_resident(s, slot_of_cur(s, cm), cur, (int)cm->bit_depth);
   t_copy += now_s() - t0;
+  g_trace.download += now_s() - t0;
+  ++g_trace.frames;
   if (gpu_copy) *gpu_copy = t_copy;
   if (gpu_run) *gpu_run = (double)ms * 1e-3;
   return 0;

@@ -213,9 +213,10 @@ def _lf_oracle(hip, oracle, planes, L, dims, bd, sharp):
 
 @pytest.mark.parametrize("W,H,bd,sharp", [(352, 288, 8, 0), (330, 250, 10, 4), (640, 360, 8, 0)])
 def test_gpu_loop_filter_and_resident_references_through_the_wrappers(harness, hip, oracle, W, H, bd, sharp):
-    """vp9hip_shim_set_gpu_loop_filter: the intra wrapper also runs phase E — masks built by the reference's
-    own vp9_build_mask (harness), adjusted and filtered on the GPU — and the decoded frame stays in the device
-    pool: the next frame references it while the HOST copy of that buffer is overwritten with garbage."""
+    """vp9hip_shim_set_gpu_loop_filter: the intra wrapper also runs phase E — masks built by the C packer
+    (pinned equal to the reference's vp9_build_mask + vp9_adjust_mask in tests/test_packer_vs_ref.py; inter
+    blocks whose eobs are all zero count as skipped, as in stock libvpx) — and the decoded frame stays in the
+    device pool: the next frame references it while the HOST copy of that buffer is overwritten with garbage."""
     rng = np.random.default_rng(W + bd)
     dt = np.uint16 if bd > 8 else np.uint8
     dims, crop = _dims(W, H)
