@@ -1,20 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py — VP9 block-reconstruction throughput on MI355X.
+"""bench.py — VP9 block-reconstruction throughput on MI355X through the PRODUCT path.
 
-A "step" is one pass of the hot path (inter prediction -> inverse transform + add -> wave-ordered
-intra prediction -> loop filter) over one synthetic 2560x1440 8-bit 4:2:0 frame whose packed work
-lists and reference frames are already resident in HBM.  BASELINE.json's configs[1]
-(Bravia.1440.ivf) cannot be used: the clip is not in the reference snapshot; the workload is the
-seeded synthetic stand-in S-1440 (cuda-vp9_amd/workload.py).  One independent stream per GPU
-(--gpus N, launched with torch.distributed.run): no data-path collective, RCCL only for the
-barrier and the end-of-batch stats reduce.
+A "step" is one pass of the hot path (inter prediction -> inverse transform + add -> wave-ordered intra
+prediction || loop filter) over one 2560x1440 8-bit 4:2:0 frame with a VP9-shaped block structure
+(tests/blockgen.py: all 13 block sizes, sub-8x8 blocks with four motion vectors, compound prediction, 4 tile
+columns, 8 % intra blocks), packed by the product's C packer (vp9hip_pack_frame) and run by the product's
+frame driver (vp9hip_decoder_run) — the code behind wrap_cuda_inter_prediction / wrap_cuda_intra_prediction.
+BASELINE.json's configs[1] (Bravia.1440.ivf) is not in the reference snapshot; S-1440 stands in.
 
-Prints ONE JSON line on rank 0.
+  value            frames/s with the frames' work lists + coefficients and the references resident in HBM
+                   (vp9hip_decoder_begin_frame done before the timed region; --frames distinct frames cycled
+                   through the decoder's ring of list sets)
+  pack_upload_run  secondary: every step also packs the frame (C packer, page-locked arrays) and uploads
+                   lists + coefficients over PCIe from a page-locked ring while the previous frame's
+                   kernels run
+  stream           secondary: the reference's own vpxdec linked against libvp9hip_shim.so decoding the
+                   synthesized S-1440 IVF end to end (CPU entropy decode included), beside the same vpxdec with
+                   the CPU wrap_cuda_* bodies; per-frame MD5s checked
+  cpu_baseline     the same frames through the REFERENCE's own C functions (oracle/_ref, ref_recon_frame)
+
+`python bench.py --gpus N` starts N ranks itself (one process per GPU, torch.distributed over RCCL, no
+data-path collective: independent streams, one per rank); under `torch.distributed.run` (RANK set) it is a
+rank.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -23,63 +38,251 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_SOURCES = {"convolve": ["inter_kernels.hip"], "idct_add": ["txfm_kernels.hip", "txfm_device.h"],
+                  "intra": ["intra_kernels.hip", "txfm_device.h"], "loop_filter": ["lf_kernels.hip"]}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=2560)
     ap.add_argument("--height", type=int, default=1440)
     ap.add_argument("--bit-depth", type=int, default=8)
-    ap.add_argument("--frames", type=int, default=4, help="distinct resident frames cycled through")
+    ap.add_argument("--frames", type=int, default=4, help="distinct resident frames cycled through (<= 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-phase-timers", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the vpxdec end-to-end leg")
     ap.add_argument("--streams", type=int, default=8,
-                    help="extra leg: this many independent streams in flight on the GPU (0 = skip); reported "
+                    help="extra leg: this many independent decoders in flight on one GPU (0 = skip); reported "
                          "under multi_stream, never as `value`")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo with --dry-run on CPU)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="host side only (launcher, stream sharding, C packer, stats reduce): no GPU is touched")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
+    return ap.parse_args()
 
-    import torch
+
+# ---------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """Parent of `--gpus N`: one child per GPU.  Nothing here initialises a GPU (device_count does not)."""
+    import socket
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(json.dumps({"error": f"--gpus {args.gpus} asked for, {have} GPU(s) visible", "n_gpus": args.gpus}))
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+def make_frames(hip, W, H, bd, stream, n):
+    """n frames of synthetic stream `stream`: decoded blocks, coefficients (reference layout), references."""
+    import numpy as np
+    import blockgen
+    import workload
+    import refframe
+    rng = np.random.default_rng(1440 + 1000 * stream)
+    dt = np.uint16 if bd > 8 else np.uint8
+    dims, _ = refframe.plane_dims(W, H)
+    refs = [[np.ascontiguousarray(workload.smooth_noise(rng, d[1], d[0], bd, sigma=1.5 + k).astype(dt)) for d in dims]
+            for k in range(3)]
+    frames = []
+    for _ in range(n):
+        blocks = blockgen.gen_blocks(rng, W, H, hip.BLOCK_DTYPE, intra_frac=0.08, skip_frac=0.35)
+        coef, eob = blockgen.gen_coeffs(rng, blocks, W, H, bd)
+        frames.append((blocks, coef, eob))
+    return refs, frames
+
+
+def frame_params(hip, W, H, bd):
+    P = hip.FrameParams()
+    P.width, P.height, P.ss_x, P.ss_y, P.bit_depth, P.hbd, P.log2_tile_cols, P.build_lf_masks = W, H, 1, 1, bd, int(bd > 8), 2, 1
+    for k in range(3):
+        P.ref_width[k], P.ref_height[k] = W, H
+    return P
+
+
+def algorithmic_bytes(L, W, H, bd):
+    """SURVEY §8(d) per-unit figures over the packed lists of one frame."""
+    import numpy as np
+    bps = 2 if bd > 8 else 1
+    it = L["inter_tasks"]
+    px = it["w"].astype(np.int64) * it["h"]
+    conv = int((px * (1 + (it["flags"] & 1))).sum() * bps + px.sum() * bps + 32 * len(it))
+    tb = L["txb"]
+    n2 = (4 << tb["tx_size"].astype(np.int64)) ** 2
+    dc = tb["eob"] <= 1
+    idct = int((np.where(dc, 1, n2) * 4).sum() + 2 * n2.sum() * bps + 16 * len(tb))
+    ia = L["intra_decode_order"]
+    bs = 4 << ia["tx_size"].astype(np.int64)
+    intra = int((bs * bs * bps).sum() + ((3 * bs + 1) * bps).sum() + 16 * len(ia) + ((ia["eob"] > 0) * bs * bs * 4).sum())
+    aw, ah = (W + 7) & ~7, (H + 7) & ~7
+    lf = int(2 * (aw * ah * 3 // 2) * bps + 160 * L["sb_rows"] * L["sb_cols"])
+    return dict(convolve=conv, idct_add=idct, intra=intra, loop_filter=lf)
+
+
+def source_hash(files):
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "cuda-vp9_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_worker(args):
+    """Child of the N-process CPU baseline: no GPU; prints frames and seconds."""
     import __graft_entry__ as g
+    import refframe
+    hip = g.load_pkg()
+    refs, frames = make_frames(hip, args.width, args.height, args.bit_depth, 0, 1)
+    rf = refframe.RefFrame(refframe.load_ref(), frames[0][0], args.width, args.height, args.bit_depth, refs,
+                           [(args.width, args.height)] * 3, frames[0][1], frames[0][2], tiles=2)
+    n, t = 0, 0.0
+    while t < args.cpu_worker or n < 2:
+        t += rf.run()
+        n += 1
+    print(json.dumps({"frames": n, "seconds": t}))
+    return 0
+
+
+def run_vpxdec(path, ivf, loops=1, md5=False, timeout=600):
+    cmd = [path] + (["--rawvideo", "--md5", "-o", "img-%wx%h-%4.i420"] if md5 else ["--noblit", "--summary", f"--loops={loops}"]) + [ivf]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    out = r.stdout.decode(errors="replace")
+    if r.returncode:
+        raise RuntimeError(f"{' '.join(cmd)} failed ({r.returncode}): {out[-400:]}")
+    if md5:
+        return [l for l in out.splitlines() if re.match(r"^[0-9a-f]{32}  img-", l)]
+    return [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"(\d+) decoded frames/\d+ showed frames in \d+ us \(([\d.]+) fps\)", out)]
+
+
+def stream_leg():
+    """The reference's vpxdec end to end on the synthesized S-1440 IVF: HIP-linked vs CPU bodies."""
+    big = os.path.join(ROOT, "tests", "streams_big")
+    ivf, gold = os.path.join(big, "S-1440.ivf"), os.path.join(big, "S-1440.md5")
+    hipdec, cdec = os.path.join(ROOT, "shim", "build", "vpxdec_hip"), os.path.join(ROOT, "oracle", "_ref", "vpx", "vpxdec_c")
+    if not all(os.path.exists(p) for p in (ivf, gold, hipdec, cdec)):
+        return {"skipped": "tests/streams_big/S-1440.ivf or the vpxdec builds are absent (tests/golden/streams/make_streams.py --big, oracle/build_refvpx.sh)"}
+    want = [l.rstrip("\n") for l in open(gold) if l.strip()]
+    got = run_vpxdec(hipdec, ivf, md5=True)
+    hip_runs = run_vpxdec(hipdec, ivf, loops=4)   # first loop pays the HIP start-up; report the warm ones
+    c_runs = run_vpxdec(cdec, ivf, loops=1)
+    warm = hip_runs[1:] or hip_runs
+    return {"stream": "S-1440 (synthesized 2560x1440 8-bit IVF, %d frames; tests/golden/streams/make_streams.py)" % len(want),
+            "md5_frames_equal": sum(a == b for a, b in zip(got, want)), "md5_frames": len(want),
+            "md5_match": got == want,
+            "vpxdec_hip_fps": round(sum(f for _, f in warm) / len(warm), 2), "vpxdec_hip_fps_first_loop": hip_runs[0][1],
+            "vpxdec_c_fps": c_runs[0][1],
+            "note": "dx_time-based fps printed by vpxdec --summary (libvpx/vpxdec.c:358-363): whole decode incl. CPU entropy "
+                    "stage, single thread; HIP = patched frame driver (INTEGRATION.md mode C)"}
+
+
+# ---------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    if args.cpu_worker > 0:
+        return cpu_worker(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as g
+    hip = g.load_pkg()
+    import cuda_vp9_amd.batch as batch
+
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dry_run:
+            dist.init_process_group(backend=args.backend)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank))
+    elif not args.dry_run:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+    dev = None if args.dry_run else torch.device("cuda", local_rank)
 
-    pkg = g.load_pkg()
-    import cuda_vp9_amd.pipeline as pipeline
-    import cuda_vp9_amd.workload as workload
-
-    ctx = pkg.Context(local_rank)
-    wls = [workload.make_frame_workload(args.width, args.height, seed=1440 + i, bd=args.bit_depth)
-           for i in range(args.frames)]
-    jobs = [pipeline.FrameJob(ctx, wl) for wl in wls]
-    ab = [pipeline.algorithmic_bytes(wl) for wl in wls]
-    PH = ("inter", "txb", "intra", "lf")
-    KN = {"inter": "convolve", "txb": "idct_add", "intra": "intra", "lf": "loop_filter"}
+    W, H, bd = args.width, args.height, args.bit_depth
+    n_frames = max(1, min(args.frames, 4))
+    # independent streams, one per GPU: stream i -> rank i mod world (SURVEY §8e)
+    my_streams = batch.shard_streams(world, rank, world)
+    refs, frames = make_frames(hip, W, H, bd, my_streams[0], n_frames)
+    P = frame_params(hip, W, H, bd)
+    th = hip.LfThresh()
+    hip.lib().vp9hip_lf_frame_init(32, 0, None, None, 0, 0, None, None, None, ctypes.byref(th))
+    pk = hip.Packer()
+    lists0 = pk.pack(P, frames[0][0], frames[0][2])
+    ab = algorithmic_bytes(lists0, W, H, bd)
+    tq0 = time.perf_counter()
+    for i in range(8):
+        pk.pack_only(P, frames[i % n_frames][0], frames[i % n_frames][2])
+    t_pack = (time.perf_counter() - tq0) / 8
+    pk.close()
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            torch.cuda.synchronize()
+
+    if args.dry_run:
+        barrier()
+        total, _, _ = batch.reduce_stats(dist, float(len(frames)), 0.0, 1.0, device=None)
+        if rank == 0:
+            print(json.dumps({"metric": "dry run: launcher + stream sharding + C packer + stats reduce, no GPU",
+                              "value": None, "n_gpus": world, "frames_packed_all_ranks": total,
+                              "streams_of_rank0": my_streams, "inter_tasks_frame0": int(len(lists0["inter_tasks"])),
+                              "host_pack_ms_per_frame": round(t_pack * 1e3, 3)}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
+
+    ALL = hip.PHASE_INTER | hip.PHASE_INTRA | hip.PHASE_LF
+    dec = hip.Decoder(local_rank)
+    for k in range(3):
+        dec.upload(k, refs[k], W, H, bd)
+    dec.alloc_slot(3, W, H, bd)
+    # coefficients in page-locked memory (what the shim hands the caller's entropy stage to write into)
+    pinned = []
+    for (blocks, coef, eob) in frames:
+        pc = []
+        for c in coef:
+            a = dec.host_array(max(1, len(c)), np.int32)
+            a[:len(c)] = c
+            pc.append(a[:len(c)])
+        pinned.append(pc)
+    sets = [dec.begin_frame(P, fr[0], fr[2], pc, persistent=True) for fr, pc in zip(frames, pinned)]
+    dec.sync()
 
     def step(i):
-        jobs[i % len(jobs)].run()  # all four phases; intra and the loop filter overlap (two HIP streams)
+        dec.select_set(sets[i % n_frames])
+        dec.run(ALL, (0, 1, 2), 3, thresh=th)
 
+    # ---- the timed region: K steps on resident lists ------------------------------------------------
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -88,142 +291,167 @@ def main():
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    dec.sync()  # reports a loop-filter row that gave up waiting, if any
 
-    # per-kernel-family GPU time: HIP events on the launch stream around each phase launched on its
-    # own (the phases of the timed steps above overlap, so they cannot be told apart there), same
-    # process, same resident frames, right after the timed region
-    timers = not args.no_phase_timers
-    n_timed = min(args.steps, 100) if timers else 0
-    phase_ms = {ph: 0.0 for ph in PH}
-    for i in range(n_timed):
-        job = jobs[i % len(jobs)]
-        for k, ph in enumerate(PH):
-            ctx.timer_begin(4 * i + k)
-            job.run(phases=(ph,))
-            ctx.timer_end(4 * i + k)
-    if n_timed:
-        ctx.sync()
-        for i in range(n_timed):
-            for k, ph in enumerate(PH):
-                phase_ms[ph] += ctx.timer_read(4 * i + k)
-    phase_ms = {ph: (v / n_timed if n_timed else None) for ph, v in phase_ms.items()}
+    # ---- secondary: pack + PCIe upload + run per step, pipelined through the ring ---------------------
+    n_pipe = max(20, args.steps // 4)
+    for i in range(4):
+        dec.begin_frame(P, frames[i % n_frames][0], frames[i % n_frames][2], pinned[i % n_frames], persistent=True)
+        dec.run(ALL, (0, 1, 2), 3, thresh=th)
+    barrier()
+    tp0 = time.perf_counter()
+    for i in range(n_pipe):
+        dec.begin_frame(P, frames[i % n_frames][0], frames[i % n_frames][2], pinned[i % n_frames], persistent=True)
+        dec.run(ALL, (0, 1, 2), 3, thresh=th)
+    barrier()
+    t_pipe = time.perf_counter() - tp0
+    dec.sync()
+    sets = [dec.begin_frame(P, fr[0], fr[2], pc, persistent=True) for fr, pc in zip(frames, pinned)]
+    dec.sync()
 
-    # ---- extra leg: several independent streams in flight on one GPU (one context = one HIP stream
-    # each).  The loop filter keeps 69 of 256 CUs busy, so frames of other streams fit beside it.
+    # ---- per-kernel GPU time: HIP events (the decoder's launch stream) around each phase on its own --
+    PH = (("convolve", hip.PHASE_INTER_PRED), ("idct_add", hip.PHASE_INTER_RESID), ("intra", hip.PHASE_INTRA),
+          ("loop_filter", hip.PHASE_LF))
+    phase_ms = {}
+    if not args.no_phase_timers:
+        n_timed = min(args.steps, 100)
+        dec.select_set(sets[0])
+        for name, bits in PH:
+            tot = 0.0
+            for _ in range(n_timed):
+                dec.run(bits, (0, 1, 2), 3, thresh=th)
+                dec.sync()
+                tot += dec.last_run_ms()
+            phase_ms[name] = tot / n_timed
+
+    # ---- correctness of what was timed: frame 0 against the reference's own C functions ---------------
+    md5_match, cpu_baseline, stream = None, None, None
+    if rank == 0:
+        import refframe
+        dec.select_set(sets[0])
+        dec.run(ALL, (0, 1, 2), 3, thresh=th)
+        dec.sync()
+        dims, _ = refframe.plane_dims(W, H)
+        got = [np.zeros((d[1], d[0]), np.uint16 if bd > 8 else np.uint8) for d in dims]
+        dec.download(3, got, W, H, bd)
+        rf = refframe.RefFrame(refframe.load_ref(), frames[0][0], W, H, bd, refs, [(W, H)] * 3, frames[0][1], frames[0][2], tiles=2)
+        t_ref = rf.run()
+        md5_match = refframe.frame_md5(got, W, H) == refframe.frame_md5(rf.planes(), W, H)
+        if world == 1 and not args.no_cpu_baseline:
+            n, t_cpu = 1, t_ref
+            while t_cpu < args.cpu_seconds:
+                t_cpu += rf.run()
+                n += 1
+            cores = min(16, os.cpu_count() or 1)
+            kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(args.cpu_seconds),
+                                      "--width", str(W), "--height", str(H), "--bit-depth", str(bd)],
+                                     stdout=subprocess.PIPE) for _ in range(cores)]
+            outs = [json.loads(k.communicate()[0].decode().strip().splitlines()[-1]) for k in kids]
+            cpu_baseline = {"value": round(n / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+                            "sample": f"{n} passes over frame 0 of the GPU run ({W}x{H}, same blocks + coefficients) through the "
+                                      f"reference's own C functions (oracle/_ref/libvpxref.so: vp9_build_inter_predictors_sb, "
+                                      f"vp9_predict_intra_block, vpx_idct*/vp9_iht*_add_c, vp9_filter_block_plane_*), one thread, {t_cpu:.1f} s",
+                            "all_cores": {"value": round(sum(o["frames"] / o["seconds"] for o in outs), 2), "cores": cores,
+                                          "sample": f"{cores} single-thread processes side by side, {args.cpu_seconds:.0f} s each"}}
+        if world == 1 and not args.no_stream:
+            try:
+                stream = stream_leg()
+            except (RuntimeError, subprocess.TimeoutExpired, OSError) as e:
+                stream = {"error": str(e)[:400]}
+
+    # ---- extra leg: several independent decoders in flight on one GPU ---------------------------------
     multi = None
     if args.streams > 1:
-        ctxs = [pkg.Context(local_rank) for _ in range(args.streams)]
-        mjobs = [[pipeline.FrameJob(c, wl) for wl in wls[:2]] for c in ctxs]
-        for w in range(3):
-            for js in mjobs:
-                js[w % len(js)].run()
-        for c in ctxs:
-            c.sync()
+        decs = []
+        for s in range(args.streams):
+            d = hip.Decoder(local_rank)
+            for k in range(3):
+                d.upload(k, refs[k], W, H, bd)
+            d.alloc_slot(3, W, H, bd)
+            d.begin_frame(P, frames[s % n_frames][0], frames[s % n_frames][2], pinned[s % n_frames], persistent=True)
+            decs.append(d)
+        for _ in range(3):
+            for d in decs:
+                d.run(ALL, (0, 1, 2), 3, thresh=th)
+        for d in decs:
+            d.sync()
         barrier()
-        n_rounds = max(10, args.steps // 4)
+        n_rounds = max(10, args.steps // 8)
         tm0 = time.perf_counter()
-        for i in range(n_rounds):
-            for js in mjobs:
-                js[i % len(js)].run()
-        for c in ctxs:
-            c.sync()
+        for _ in range(n_rounds):
+            for d in decs:
+                d.run(ALL, (0, 1, 2), 3, thresh=th)
+        for d in decs:
+            d.sync()
         barrier()
         tm = time.perf_counter() - tm0
-        multi = {"streams": args.streams, "frames": n_rounds * args.streams,
-                 "frames_per_s": round(n_rounds * args.streams / tm, 1)}
-        multi_got = [js[0].download() for js in mjobs] if rank == 0 else None  # checked against the oracle below
-        for js in mjobs:
-            for j in js:
-                j.free()
-        for c in ctxs:
-            c.close()
-
-    # correctness of what was timed: frame 0 against the oracle (rank 0 only; small CPU cost)
-    md5_match = None
-    cpu_baseline = None
-    if rank == 0:
-        import frame_check
-        oracle = frame_check.load_oracle()
-        jobs[0].run()  # the phase-timing loop above re-ran single phases on the frame: rebuild it
-        ctx.sync()
-        got = jobs[0].download()
-        exp, _ = frame_check.oracle_frame(oracle, wls[0])
-        md5_match = frame_check.frame_md5(got, wls[0]) == frame_check.frame_md5(exp, wls[0])
-        if multi is not None:
-            multi["md5_match_vs_oracle"] = all(frame_check.frame_md5(g_, wls[0]) == frame_check.frame_md5(exp, wls[0])
-                                               for g_ in multi_got)
-        if world == 1 and not args.no_cpu_baseline:
-            n, t_cpu = 0, 0.0
-            while t_cpu < args.cpu_seconds or n < 2:
-                _, times = frame_check.oracle_frame(oracle, wls[n % len(wls)])
-                t_cpu += sum(times.values())
-                n += 1
-            cpu_baseline = {"value": round(n / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                            "sample": f"{n} synthetic {args.width}x{args.height} frames (same work lists as the GPU "
-                                      f"run) through oracle/ C restatement, single thread, {t_cpu:.1f} s"}
+        multi = {"streams": args.streams, "frames": n_rounds * args.streams, "frames_per_s": round(n_rounds * args.streams / tm, 1)}
+        for d in decs:
+            d.close()
 
     # stats reduce: total frames (sum) and slowest rank (max) — the only collective in the harness
-    import cuda_vp9_amd.batch as batch
-    frames_total, _, t_max = batch.reduce_stats(dist, args.steps, 0.0, elapsed,
-                                                device=torch.device("cuda", local_rank))
-    if multi is not None:
-        m_total, _, _ = batch.reduce_stats(dist, multi["frames_per_s"], 0.0, 0.0, device=torch.device("cuda", local_rank))
-        multi["frames_per_s_all_gpus"] = round(m_total, 1)
+    frames_total, _, t_max = batch.reduce_stats(dist, args.steps, 0.0, elapsed, device=dev)
+    pipe_total, _, t_pipe_max = batch.reduce_stats(dist, n_pipe, 0.0, t_pipe, device=dev)
 
     if rank == 0:
         kernels = {}
-        if n_timed:
-            for ph in PH:
-                byts = sum(a[KN[ph]] for a in ab) / len(ab)
-                ms = phase_ms[ph]
-                gbs = byts / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
-                kernels[KN[ph]] = {"ms_per_frame": round(ms, 5), "algorithmic_bytes": int(byts),
-                                   "GB/s": round(gbs, 1) if gbs else None,
-                                   "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5) if gbs else None}
+        for name, _ in PH:
+            if name in phase_ms:
+                ms = phase_ms[name]
+                gbs = ab[name] / (ms * 1e-3) / 1e9 if ms > 0 else None
+                kernels[name] = {"ms_per_frame": round(ms, 5), "algorithmic_bytes": ab[name], "GB/s": round(gbs, 1) if gbs else None,
+                                 "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5) if gbs else None}
         roofline = None
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])
-            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-            # runs of the same workload, tools/pmc_collect.sh; FETCH_SIZE doubled as calibrated on gfx950 with
-            # tools/fetch_calibrate.hip) — measured offline, committed under profiles/
-            traffic, pmc = None, {}
+            # HBM bytes per launch from rocprofv3 --pmc passes of tools/pmc_collect.sh (FETCH_SIZE x2 as calibrated
+            # on gfx950, WRITE_SIZE); quoted only while the kernel's source is what was profiled
+            traffic, note = None, "no PMC record"
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
                 e = pmc.get(dom)
-                if e and args.width == 2560 and args.height == 1440 and args.bit_depth == 8:
-                    traffic = int(e["hbm_read_bytes_gfx950_x2"] + e["hbm_write_bytes"])
+                if e and (W, H, bd) == (2560, 1440, 8):
+                    if e.get("source_sha256") == source_hash(KERNEL_SOURCES[dom]):
+                        traffic = int(e["hbm_read_bytes_gfx950_x2"] + e["hbm_write_bytes"])
+                        note = f"profiles/pmc_current.json ({e.get('collected', 'round 2')}), kernel source hash matches"
+                    else:
+                        note = "profiles/pmc_current.json was collected on an older version of this kernel: not quoted"
+                for k, v in kernels.items():
+                    e = pmc.get(k)
+                    if e and e.get("source_sha256") == source_hash(KERNEL_SOURCES[k]):
+                        v["hbm_traffic_bytes_pmc"] = int(e["hbm_read_bytes_gfx950_x2"] + e["hbm_write_bytes"])
+                        if "lds_bank_conflict_frac" in e:
+                            v["lds_bank_conflict_frac_pmc"] = e["lds_bank_conflict_frac"]
             except (OSError, KeyError, ValueError):
                 pass
-            for k, v in kernels.items():
-                e = pmc.get(k)
-                if e and traffic is not None:
-                    v["hbm_traffic_bytes_pmc"] = int(e["hbm_read_bytes_gfx950_x2"] + e["hbm_write_bytes"])
-                    e2 = pmc.get(k + "_residual")  # the intra phase is two kernels: residual pre-pass + walk
-                    if e2:
-                        v["hbm_traffic_bytes_pmc"] += int(e2["hbm_read_bytes_gfx950_x2"] + e2["hbm_write_bytes"])
-                    if "lds_bank_conflict_frac" in e:
-                        v["lds_bank_conflict_frac_pmc"] = e["lds_bank_conflict_frac"]
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic}
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": note}
+        blocks0 = frames[0][0]
         out = {
             "metric": "decoded frames/sec (block-reconstruction path: inter+idct+intra+loop filter), 1440p VP9 8-bit",
             "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8" if args.bit_depth == 8 else "u16",
-            "data": "synthetic",
-            "config": {"workload": f"S-{args.height}: synthetic {args.width}x{args.height} {args.bit_depth}-bit 4:2:0 "
-                                   f"inter frame ({wls[0]['n_blocks']} blocks, {len(wls[0]['inter_tasks'])} inter tasks, "
-                                   f"{len(wls[0]['txb'])} coded inter tx blocks, {len(wls[0]['intra_sorted'])} intra tx "
-                                   f"blocks in {wls[0]['n_waves']} waves, {wls[0]['sb_rows']}x{wls[0]['sb_cols']} SBs), "
-                                   f"{args.frames} distinct frames resident in HBM, one stream per GPU",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8" if bd == 8 else "u16", "data": "synthetic",
+            "config": {"workload": f"S-{H}: synthetic {W}x{H} {bd}-bit 4:2:0 inter frames with a VP9 partition ({len(blocks0)} "
+                                   f"blocks, {len(lists0['inter_tasks'])} inter tasks, {len(lists0['txb'])} coded inter tx blocks, "
+                                   f"{len(lists0['intra_decode_order'])} intra tx blocks in {lists0['n_waves']} waves, "
+                                   f"{lists0['sb_rows']}x{lists0['sb_cols']} SBs) packed by vp9hip_pack_frame, run by "
+                                   f"vp9hip_decoder_run; {n_frames} distinct frames resident in HBM, one stream per GPU",
                        "parallelism": f"streams{world}"},
-            "md5_match_vs_oracle": md5_match,
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_baseline, "multi_stream": multi,
+            "md5_match_vs_reference_c": md5_match,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_baseline,
+            "pack_upload_run": {"frames_per_s": round(pipe_total / t_pipe_max, 1), "frames": n_pipe,
+                                "host_pack_ms_per_frame": round(t_pack * 1e3, 3),
+                                "note": "every step packs the frame on the host and uploads lists + coefficients from "
+                                        "page-locked memory (ring of 4 list sets) while the previous frame's kernels run"},
+            "stream": stream, "multi_stream": multi,
         }
         print(json.dumps(out))
+    dec.close()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

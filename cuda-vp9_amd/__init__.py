@@ -93,7 +93,7 @@ class HostFrame(ctypes.Structure):
                 ("bit_depth", ctypes.c_int32), ("hbd", ctypes.c_int32)]
 
 
-PHASE_INTER, PHASE_INTRA, PHASE_LF = 1, 2, 4
+PHASE_INTER, PHASE_INTRA, PHASE_LF, PHASE_INTER_PRED, PHASE_INTER_RESID = 1, 2, 4, 8, 16
 
 
 class LfThresh(ctypes.Structure):
@@ -270,7 +270,11 @@ class Packer:
         if lib().vp9hip_packer_create(ctypes.byref(self.handle)) != 0:
             raise Vp9HipError("vp9hip_packer_create failed")
 
-    def pack(self, params: FrameParams, blocks, eob_planes=None):
+    def pack_only(self, params: FrameParams, blocks, eob_planes=None):
+        """vp9hip_pack_frame without copying the lists out (host packing time measurements)."""
+        return self.pack(params, blocks, eob_planes, copy=False)
+
+    def pack(self, params: FrameParams, blocks, eob_planes=None, copy=True):
         """blocks: BLOCK_DTYPE array in decode order; eob_planes: three int32 2-D arrays indexed [y, x]
         (the reference's plane_eob layout) or None.  Returns a dict of numpy copies of the lists."""
         blocks = np.ascontiguousarray(blocks, BLOCK_DTYPE)
@@ -289,6 +293,8 @@ class Packer:
         if rc != 0:
             raise Vp9HipError(f"vp9hip_pack_frame failed ({rc}): {lib().vp9hip_packer_error(self.handle).decode()}")
         n_sb = out.sb_rows * out.sb_cols
+        if not copy:
+            return out.n_inter
         return dict(
             inter_tasks=_arr(out.inter, out.n_inter, INTER_DTYPE), inter_class_count=list(out.inter_class_count),
             txb=_arr(out.txb, out.n_txb, TXB_DTYPE), txb_counts=list(out.txb_size_count),

@@ -453,8 +453,10 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
                                              (const vp9hip_intra_island *)S->d_islands.p, P->n_islands,
                                              (const int32_t *)S->d_wave_off.p, (const int32_t *)S->d_coeffs.p, dst));
 
-  if ((phases & VP9HIP_PHASE_INTER)) {
-    if (P->n_inter) {
+  const bool do_pred = (phases & (VP9HIP_PHASE_INTER | VP9HIP_PHASE_INTER_PRED)) != 0;
+  const bool do_resid = (phases & (VP9HIP_PHASE_INTER | VP9HIP_PHASE_INTER_RESID)) != 0;
+  if (do_pred || do_resid) {
+    if (do_pred && P->n_inter) {
       vp9hip_frame refs[3];
       memset(refs, 0, sizeof(refs));
       for (int k = 0; k < 3; ++k) {
@@ -475,7 +477,8 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
       }
       DEC_CTX(dec, vp9hip_inter_pred_batch(dec->ctx, (const vp9hip_inter_task *)S->d_inter.p, P->inter_class_count, refs, 3, dst));
     }
-    if (dec->have_res) {
+    if (!do_resid) {
+    } else if (dec->have_res) {
       for (int p = 0; p < 3; ++p) {
         const int w = dst->awidth[p], h = dst->aheight[p];
         hipLaunchKernelGGL(residual_add_plane_kernel, dim3((w / 2 + 255) / 256, h), dim3(256), 0, st, (uint16_t *)dst->plane[p],

@@ -90,6 +90,9 @@ int vp9hip_decoder_set_residual_planes(vp9hip_decoder *dec, const int64_t *const
 #define VP9HIP_PHASE_INTER 1 /* inter prediction + residual of inter blocks */
 #define VP9HIP_PHASE_INTRA 2 /* wave-ordered intra prediction + residual */
 #define VP9HIP_PHASE_LF 4    /* loop filter (needs params.build_lf_masks or an explicit lfm) */
+/* halves of VP9HIP_PHASE_INTER on their own (per-kernel timing): prediction / residual of inter blocks */
+#define VP9HIP_PHASE_INTER_PRED 8
+#define VP9HIP_PHASE_INTER_RESID 16
 
 /* Enqueue phases for the frame begun last, reading references from pool slots ref_slot[0..2]
  * (LAST, GOLDEN, ALTREF; -1 = unused) and reconstructing into dst_slot.  h_lfm (HOST, sb_rows *

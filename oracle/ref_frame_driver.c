@@ -329,3 +329,207 @@ void ref_lf_levels(int default_lvl, int sharpness, const int32_t seg_enabled[8],
   }
   free(cm);
 }
+
+/* ---- one whole frame through the reference's C functions ------------------------------------------
+ * ref_recon_frame: what the reference's decoder does to a frame after parsing it, block by block in
+ * decode order (stock order, libvpx/vp9/decoder/vp9_decodeframe.c:1073-1196 run per block): inter blocks
+ * = vp9_build_inter_predictors_sb then the inverse transform + add of every coded transform block; intra
+ * blocks = per transform block vp9_predict_intra_block then inverse transform + add; then, when
+ * filter != 0, vp9_build_mask per block (with libvpx's `eobtotal == 0 -> skip`, :1195) + vp9_adjust_mask +
+ * vp9_filter_block_plane_ss00 / ss11 per superblock.  Used as the CPU baseline of bench.py (kind
+ * "reference") and as the expected frame of the GPU frame tests — independent of the product's packers.
+ *
+ * coefs[p]: concatenated N*N blocks in decode order, one slot per visited transform block of every
+ * non-skip block (detoken_block's layout, :919-1024); eobs[p]: frame-strided plane, one int at each
+ * transform block's origin.  Transform selection by eob as vp9_idct{4x4,8x8,16x16,32x32}_add /
+ * vp9_iht*_add do it (libvpx/vp9/common/vp9_idct.c:119-204); high-bitdepth buffers take the fork's
+ * residual-storing full transforms + highbd_clip_pixel_add, the composition its phase B + block_sum make
+ * (:173-341). */
+#include "./vp9_rtcd.h"
+#include "vpx_dsp/inv_txfm.h"
+
+typedef struct {
+  MACROBLOCKD *xd;
+  const int32_t *const *eobs;
+  const int *eob_strides;
+  const int32_t *coef[3];
+  int mi_row, mi_col, ss, lossless, intra, eobtotal;
+} recon_arg;
+
+static void ref_inverse_add(MACROBLOCKD *xd, TX_SIZE tx_size, TX_TYPE tx_type, const tran_low_t *dq, int eob, uint8_t *dst,
+                            int stride, int lossless) {
+  if (xd->cur_buf->flags & YV12_FLAG_HIGHBITDEPTH) {
+    tran_high_t res[32 * 32];
+    const int n = 4 << tx_size;
+    uint16_t *d = CONVERT_TO_SHORTPTR(dst);
+    switch (tx_size) {
+      case TX_4X4:
+        if (tx_type == DCT_DCT) vpx_highbd_idct4x4_16_add_c(dq, res, n, xd->bd);
+        else vp9_highbd_iht4x4_16_add_c(dq, res, n, tx_type, xd->bd);
+        break;
+      case TX_8X8:
+        if (tx_type == DCT_DCT) vpx_highbd_idct8x8_64_add_c(dq, res, n, xd->bd);
+        else vp9_highbd_iht8x8_64_add_c(dq, res, n, tx_type, xd->bd);
+        break;
+      case TX_16X16:
+        if (tx_type == DCT_DCT) vpx_highbd_idct16x16_256_add_c(dq, res, n, xd->bd);
+        else vp9_highbd_iht16x16_256_add_c(dq, res, n, tx_type, xd->bd);
+        break;
+      default: vpx_highbd_idct32x32_1024_add_c(dq, res, n, xd->bd); break;
+    }
+    for (int y = 0; y < n; ++y)
+      for (int x = 0; x < n; ++x) d[y * stride + x] = highbd_clip_pixel_add(d[y * stride + x], res[y * n + x], xd->bd);
+    return;
+  }
+  if (lossless) {
+    if (eob > 1) vpx_iwht4x4_16_add_c(dq, dst, stride);
+    else vpx_iwht4x4_1_add_c(dq, dst, stride);
+    return;
+  }
+  switch (tx_size) {
+    case TX_4X4:
+      if (tx_type != DCT_DCT) vp9_iht4x4_16_add_c(dq, dst, stride, tx_type);
+      else if (eob > 1) vpx_idct4x4_16_add_c(dq, dst, stride);
+      else vpx_idct4x4_1_add_c(dq, dst, stride);
+      break;
+    case TX_8X8:
+      if (tx_type != DCT_DCT) vp9_iht8x8_64_add_c(dq, dst, stride, tx_type);
+      else if (eob == 1) vpx_idct8x8_1_add_c(dq, dst, stride);
+      else if (eob <= 12) vpx_idct8x8_12_add_c(dq, dst, stride);
+      else vpx_idct8x8_64_add_c(dq, dst, stride);
+      break;
+    case TX_16X16:
+      if (tx_type != DCT_DCT) vp9_iht16x16_256_add_c(dq, dst, stride, tx_type);
+      else if (eob == 1) vpx_idct16x16_1_add_c(dq, dst, stride);
+      else if (eob <= 10) vpx_idct16x16_10_add_c(dq, dst, stride);
+      else if (eob <= 38) vpx_idct16x16_38_add_c(dq, dst, stride);
+      else vpx_idct16x16_256_add_c(dq, dst, stride);
+      break;
+    default:
+      if (eob == 1) vpx_idct32x32_1_add_c(dq, dst, stride);
+      else if (eob <= 34) vpx_idct32x32_34_add_c(dq, dst, stride);
+      else if (eob <= 135) vpx_idct32x32_135_add_c(dq, dst, stride);
+      else vpx_idct32x32_1024_add_c(dq, dst, stride);
+      break;
+  }
+}
+
+static void recon_visit(int plane, int block, int row, int col, BLOCK_SIZE plane_bsize, TX_SIZE tx_size, void *argp) {
+  recon_arg *a = (recon_arg *)argp;
+  MACROBLOCKD *xd = a->xd;
+  struct macroblockd_plane *pd = &xd->plane[plane];
+  const MODE_INFO *mi = xd->mi[0];
+  const int stride = pd->dst.stride, s = plane ? a->ss : 0;
+  PREDICTION_MODE mode = plane == 0 ? mi->mode : mi->uv_mode;
+  uint8_t *dst;
+  (void)block;
+  (void)plane_bsize;
+  if (xd->cur_buf->flags & YV12_FLAG_HIGHBITDEPTH)
+    dst = CONVERT_TO_BYTEPTR(CONVERT_TO_SHORTPTR(pd->dst.buf) + 4 * row * stride + 4 * col);
+  else
+    dst = &pd->dst.buf[4 * row * stride + 4 * col];
+  if (a->intra) {
+    if (mi->sb_type < BLOCK_8X8 && plane == 0) mode = mi->bmi[(row << 1) + col].as_mode;
+    vp9_predict_intra_block(xd, pd->n4_wl, tx_size, mode, dst, stride, dst, stride, col, row, plane);
+  }
+  if (!mi->skip) {
+    const int x = ((a->mi_col * 8) >> s) + 4 * col, y = ((a->mi_row * 8) >> s) + 4 * row;
+    const int eob = a->eobs[plane][(size_t)y * a->eob_strides[plane] + x];
+    const TX_TYPE tx_type = (!a->intra || plane || a->lossless || tx_size == TX_32X32) ? DCT_DCT : intra_mode_to_tx_type_lookup[mode];
+    if (eob > 0) ref_inverse_add(xd, tx_size, tx_type, (const tran_low_t *)a->coef[plane], eob, dst, stride, a->lossless);
+    a->eobtotal += eob;
+    a->coef[plane] += 16 << (tx_size << 1);
+  }
+}
+
+int ref_recon_frame(const int32_t *blocks, int n_blocks, int w, int h, int ss, int bd, int hbd, void *const cur_planes[3],
+                    const int cur_strides[3], void *const ref_planes[9], const int ref_strides[9], const int ref_w[3],
+                    const int ref_h[3], const int32_t *const coefs[3], const int32_t *const eobs[3], const int eob_strides[3],
+                    int log2_tile_cols, int lossless, int filter, int sharpness) {
+  static int inited = 0;
+  const int mi_rows = ((h + 7) & ~7) / 8, mi_cols = ((w + 7) & ~7) / 8;
+  YV12_BUFFER_CONFIG cur, refbuf[3];
+  RefBuffer rb[3];
+  MODE_INFO dummy;
+  VP9_COMMON *cm = (VP9_COMMON *)calloc(1, sizeof(*cm));
+  MACROBLOCKD *xd = (MACROBLOCKD *)calloc(1, sizeof(*xd));
+  uint8_t *lf_skip = (uint8_t *)malloc((size_t)n_blocks + 1);
+  recon_arg arg;
+  if (!cm || !xd || !lf_skip) return -1;
+  if (!inited) {
+    vp9_init_intra_predictors();
+    inited = 1;
+  }
+  memset(&dummy, 0, sizeof(dummy));
+  memset(&arg, 0, sizeof(arg));
+  cm->mi_rows = mi_rows;
+  cm->mi_cols = mi_cols;
+  cm->log2_tile_cols = log2_tile_cols;
+  fill_yv12(&cur, cur_planes, cur_strides, w, h, ss, hbd, bd);
+  memset(rb, 0, sizeof(rb));
+  for (int k = 0; k < 3; ++k) {
+    if (ref_w[k] <= 0) continue;
+    fill_yv12(&refbuf[k], &ref_planes[3 * k], &ref_strides[3 * k], ref_w[k], ref_h[k], ss, hbd, bd);
+    rb[k].buf = &refbuf[k];
+    rb[k].idx = k;
+    vp9_setup_scale_factors_for_frame(&rb[k].sf, ref_w[k], ref_h[k], w, h, hbd);
+    if (!vp9_is_valid_scale(&rb[k].sf)) return -2;
+  }
+  xd->cur_buf = &cur;
+  xd->bd = bd;
+  arg.xd = xd;
+  arg.eobs = eobs;
+  arg.eob_strides = eob_strides;
+  arg.ss = ss;
+  arg.lossless = lossless;
+  for (int p = 0; p < 3; ++p) arg.coef[p] = coefs[p];
+  for (int i = 0; i < n_blocks; ++i) {
+    const int32_t *b = blocks + REC * i;
+    MODE_INFO mi, *mip = &mi;
+    TileInfo tile;
+    fill_mi(&mi, b);
+    const BLOCK_SIZE bsize = mi.sb_type < BLOCK_8X8 ? BLOCK_8X8 : mi.sb_type;
+    const int bw8 = num_8x8_blocks_wide_lookup[bsize], bh8 = num_8x8_blocks_high_lookup[bsize];
+    xd->mi = &mip;
+    set_block_geometry(xd, b[0], b[1], bw8, bh8, mi_rows, mi_cols, ss);
+    for (int t = 0; t < (1 << log2_tile_cols); ++t) {
+      vp9_tile_set_col(&tile, cm, t);
+      if (b[1] >= tile.mi_col_start && b[1] < tile.mi_col_end) break;
+    }
+    xd->above_mi = (b[0] != 0) ? &dummy : NULL;
+    xd->left_mi = (b[1] > tile.mi_col_start) ? &dummy : NULL;
+    vp9_setup_dst_planes(xd->plane, &cur, b[0], b[1]);
+    arg.mi_row = b[0];
+    arg.mi_col = b[1];
+    arg.intra = b[6] <= 0;
+    arg.eobtotal = 0;
+    if (!arg.intra) {
+      for (int r = 0; r < 1 + has_second_ref(&mi); ++r) {
+        RefBuffer *ref_buf = &rb[mi.ref_frame[r] - LAST_FRAME];
+        xd->block_refs[r] = ref_buf;
+        vp9_setup_pre_planes(xd, r, ref_buf->buf, b[0], b[1], &ref_buf->sf);
+      }
+      vp9_build_inter_predictors_sb(xd, b[0], b[1], bsize);
+    }
+    if (arg.intra || !mi.skip)
+      for (int plane = 0; plane < MAX_MB_PLANE; ++plane)
+        vp9_foreach_transformed_block_in_plane(xd, bsize, plane, recon_visit, &arg);
+    lf_skip[i] = (uint8_t)(mi.skip || (!arg.intra && mi.sb_type >= BLOCK_8X8 && arg.eobtotal == 0));
+  }
+  free(xd);
+  free(cm);
+  if (filter) {
+    /* masks + filtering exactly as ref_lf_frame2, with the skip flags as libvpx's loop filter sees them */
+    int32_t *b2 = (int32_t *)malloc(sizeof(int32_t) * REC * (size_t)(n_blocks + 1));
+    void *lfm = malloc((size_t)((mi_rows + 7) / 8) * ((mi_cols + 7) / 8) * sizeof(LOOP_FILTER_MASK));
+    if (!b2 || !lfm) return -1;
+    memcpy(b2, blocks, sizeof(int32_t) * REC * (size_t)n_blocks);
+    for (int i = 0; i < n_blocks; ++i) b2[REC * i + 4] = lf_skip[i];
+    const int rc = ref_lf_frame2(b2, n_blocks, mi_cols * 8, mi_rows * 8, cur_planes, cur_strides, bd, hbd, sharpness, lfm, 1);
+    free(b2);
+    free(lfm);
+    if (rc < 0) return rc;
+  }
+  free(lf_skip);
+  return 0;
+}

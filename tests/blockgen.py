@@ -133,7 +133,7 @@ def uv_tx(sb_type, tx_size):
     return min(int(tx_size), int(np.log2(m)))
 
 
-def gen_coeffs(rng, blocks, width, height, bd, eob_stride_pad=0, amp=1.0, lossless=False):
+def gen_coeffs(rng, blocks, width, height, bd, eob_stride_pad=0, amp=1.0, lossless=False, zero_frac=0.2):
     """Coefficients in the reference's layout: per plane one concatenated array (a slot for every
     visited transform block of every non-skip block) + frame-strided eob planes.
     Returns (coef[3], eob[3])."""
@@ -161,6 +161,10 @@ def gen_coeffs(rng, blocks, width, height, bd, eob_stride_pad=0, amp=1.0, lossle
                     y = ((int(b["mi_row"]) * 8) >> ss) + 4 * row
                     blk = np.zeros((n, n), np.int32)
                     r = rng.random()
+                    if r < zero_frac:
+                        r = 0.0
+                    else:
+                        r = 0.2 + 0.8 * (r - zero_frac) / (1.0 - zero_frac)
                     if r < 0.2:
                         e = 0
                     elif r < 0.5:

@@ -15,7 +15,7 @@ def run(verbose=False):
     import frame_check
     pkg = g.load_pkg()
     import cuda_vp9_amd.pipeline as pipeline
-    import cuda_vp9_amd.workload as workload
+    import workload
     wl = workload.make_frame_workload(352, 288, seed=7, bd=8, intra_frac=0.2)
     ctx = pkg.Context(0)
     job = pipeline.FrameJob(ctx, wl)

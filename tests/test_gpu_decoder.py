@@ -88,7 +88,7 @@ def _oracle_frame(hip, oracle, P, blocks, coef, eob, refs, W, H, bd, th):
     (72, 16, 8, 0, 0, {}),
 ])
 def test_decoder_three_phases_match_oracle(hip, oracle, W, H, bd, tiles, sharp, kw):
-    import cuda_vp9_amd.workload as workload
+    import workload
     rng = np.random.default_rng(W * 7 + H + bd)
     dt = np.uint16 if bd > 8 else np.uint8
     dims, crop = _dims(W, H)

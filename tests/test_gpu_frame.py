@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
     (1920, 1080, 10, {}),
 ])
 def test_frame_pipeline_matches_oracle(hip, oracle, W, H, bd, kw):
-    import cuda_vp9_amd.workload as workload
+    import workload
     import cuda_vp9_amd.pipeline as pipeline
     wl = workload.make_frame_workload(W, H, seed=W + H + bd, bd=bd, **kw)
     ctx = hip.Context(0)
@@ -55,7 +55,7 @@ def test_loop_filter_handoff_is_stable_under_repetition(hip, oracle):
     """The row-walking loop filter hands pixels between workgroups inside one launch; a stale
     read would show up as a run-to-run difference.  40 repetitions on a 1440p frame, each compared
     with the (deterministic) oracle result."""
-    import cuda_vp9_amd.workload as workload
+    import workload
     import cuda_vp9_amd.pipeline as pipeline
     wl = workload.make_frame_workload(2560, 1440, seed=99)
     ctx = hip.Context(0)

@@ -122,7 +122,7 @@ def test_intra_islands_match_sequential_oracle(hip, oracle):
     """Island form (one launch, one workgroup per connected component) on an inter frame with
     intra clusters and on an all-intra frame: same pixels as the oracle run in decode order."""
     import cuda_vp9_amd.pipeline as pipeline
-    import cuda_vp9_amd.workload as workload
+    import workload
     import frame_check
     for kw in (dict(intra_frac=0.4), dict(all_intra=True)):
         wl = workload.make_frame_workload(328, 200, seed=11, **kw)

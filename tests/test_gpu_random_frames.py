@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_random_frames_match_oracle(hip, oracle):
-    import cuda_vp9_amd.workload as workload
+    import workload
     n = int(os.environ.get("VP9HIP_RANDOM_FRAMES", "24"))
     rng = np.random.default_rng(20261004)
     dec = hip.Decoder(0)

@@ -147,7 +147,7 @@ def _run(harness, hip, oracle, W, H, bd, seed, *, inter=True, coefficient_mode=T
 
 
 def blockgen_noise(rng, h, w, bd):
-    import cuda_vp9_amd.workload as workload
+    import workload
     return workload.smooth_noise(rng, h, w, bd, sigma=1.5)
 
 

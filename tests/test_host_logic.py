@@ -8,7 +8,7 @@ import pytest
 
 
 def test_lf_masks_are_exclusive_and_trimmed(hip):
-    import cuda_vp9_amd.workload as workload
+    import workload
     for (W, H) in [(352, 288), (200, 136), (328, 72)]:
         wl = workload.make_frame_workload(W, H, seed=W)
         aw, ah = wl["dims"][0]
@@ -30,7 +30,7 @@ def test_lf_masks_are_exclusive_and_trimmed(hip):
 
 
 def test_intra_waves_respect_dependencies(hip):
-    import cuda_vp9_amd.workload as workload
+    import workload
     wl = workload.make_frame_workload(320, 192, seed=5, intra_frac=0.6)
     tasks = wl["intra_decode_order"]
     lv = workload.intra_levels(tasks, wl["dims"])
@@ -94,3 +94,30 @@ def test_stats_reduce_gloo_world2(hip):
         assert p.exitcode == 0
     for (_, total, fails, tmax) in res:
         assert total == 500.0 and fails == 1.0 and tmax == 2.0
+
+
+def test_bench_launches_its_own_ranks_gloo_dry_run():
+    """`python bench.py --gpus 2` is self-contained: the parent starts one rank per GPU (here: per CPU
+    process, gloo, --dry-run = launcher + stream sharding + C packer + stats reduce, no GPU call)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo",
+                        "--width", "352", "--height", "288", "--frames", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["frames_packed_all_ranks"] == 4.0 and out["streams_of_rank0"] == [0]
+
+
+def test_bench_refuses_more_gpus_than_visible_cleanly():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 2
+    assert "GPU(s) visible" in json.loads(r.stdout.decode().strip().splitlines()[-1])["error"]

@@ -14,7 +14,7 @@ from frame_check import OThresh
 @pytest.mark.parametrize("W,H,bd,sharp,seed", [(352, 288, 8, 0, 1), (200, 136, 8, 3, 2), (328, 72, 10, 0, 3),
                                                 (640, 360, 8, 5, 4), (136, 200, 12, 7, 5)])
 def test_masks_and_filtering_match_reference_driver(hip, oracle, ref, W, H, bd, sharp, seed):
-    import cuda_vp9_amd.workload as workload
+    import workload
     wl = workload.make_frame_workload(W, H, seed=seed, bd=bd, sharpness=sharp, intra_frac=0.2)
     hbd = bd > 8
     dt = np.uint16 if hbd else np.uint8

@@ -244,9 +244,8 @@ def test_island_and_wave_lists_preserve_dependencies(hip, oracle, W, H, kw, seed
 def test_island_superblock_marks(hip, W, H, kw, seed):
     """vp9hip_intra_islands_lf hand-over data: per island exactly the LAST task (list order) inside each luma
     superblock carries bit 0 of `reserved`, island_sb_expected counts the marks per superblock, and the
-    Python mirror used by bench.py (workload.island_sb_expected) produces the same marks and counts."""
-    import importlib
-    workload = importlib.import_module(hip.__name__ + ".workload")
+    Python mirror the kernel-level tests use (tests/workload.island_sb_expected) produces the same marks and counts."""
+    import workload
     rng = np.random.default_rng(seed)
     blocks = blockgen.gen_blocks(rng, W, H, hip.BLOCK_DTYPE, **kw)
     pk = hip.Packer()

@@ -1,4 +1,5 @@
-"""workload.py — synthetic frame workloads + host-side packing of the work lists.
+"""workload.py — TEST INFRASTRUCTURE: synthetic frame workloads + a Python packing of the work lists
+(predates the C packer; kept for the kernel-level tests, which want lists they control).
 
 Produces, for one frame, exactly what libvpx's entropy stage would hand to the reconstruction
 path: a partition into prediction blocks (modes, references, motion vectors, transform sizes,
@@ -19,7 +20,7 @@ in the reference snapshot and no encoder is available, so the data is synthetic 
 """
 import numpy as np
 
-from . import INTER_DTYPE, INTRA_DTYPE, LFM_DTYPE, TXB_DTYPE
+from cuda_vp9_amd import INTER_DTYPE, INTRA_DTYPE, LFM_DTYPE, TXB_DTYPE
 
 # intra_mode_to_tx_type_lookup (vp9_reconintra.c:24-35): DC V H D45 D135 D117 D153 D207 D63 TM
 MODE_TO_TX_TYPE = np.array([0, 1, 2, 0, 3, 1, 2, 2, 1, 3], np.uint8)
@@ -280,7 +281,7 @@ def island_sb_expected(isl_tasks, islands, sb_rows, sb_cols):
 def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
     """Split the intra tasks into islands (one workgroup each, vp9hip_intra_pred_islands) and a
     remainder of very large components that keeps the per-wave launches."""
-    from . import ISLAND_DTYPE
+    from cuda_vp9_amd import ISLAND_DTYPE
     n = len(tasks)
     if n == 0:
         return (tasks, np.zeros(0, ISLAND_DTYPE), np.zeros(1, np.int32), tasks, np.zeros(1, np.int32))

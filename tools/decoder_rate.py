@@ -10,7 +10,7 @@ import numpy as np
 import __graft_entry__ as g
 hip = g.load_pkg()
 import blockgen
-import cuda_vp9_amd.workload as workload
+import workload
 W, H = 2560, 1440
 bd = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rng = np.random.default_rng(3)

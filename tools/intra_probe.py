@@ -3,12 +3,12 @@
 Variants of the same 1440p frame: as is / prediction only (eob = 0) / all DC mode / both."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_pkg()
 import cuda_vp9_amd.pipeline as pipeline
-import cuda_vp9_amd.workload as workload
+import workload
 ctx = pkg.Context(0)
 base = workload.make_frame_workload(2560, 1440, seed=1440)
 isl = base["intra_islands"]

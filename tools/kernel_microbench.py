@@ -5,11 +5,11 @@ by-area mix), dense (eob = N*N) or DC-only; algorithmic bytes = 4*N*N (or 4) + 2
 K-lpf: uniform random frame, level 32, masks of a random partition; 2*P*bps + 160 B per superblock."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_pkg()
-import cuda_vp9_amd.workload as workload
+import workload
 ctx = pkg.Context(0)
 rng = np.random.default_rng(11)
 out = []

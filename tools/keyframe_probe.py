@@ -2,11 +2,11 @@
 """Time of an all-intra (key) frame through the pipeline, by phase."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as g
 pkg = g.load_pkg()
 import cuda_vp9_amd.pipeline as pipeline
-import cuda_vp9_amd.workload as workload
+import workload
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2560, 1440)
 ctx = pkg.Context(0)
 wl = workload.make_frame_workload(W, H, seed=5, all_intra=True)

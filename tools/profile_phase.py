@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 ap = argparse.ArgumentParser()
 ap.add_argument("--phase", default="inter")
 ap.add_argument("--steps", type=int, default=20)
@@ -20,7 +20,7 @@ args = ap.parse_args()
 import __graft_entry__ as g  # noqa: E402
 pkg = g.load_pkg()
 import cuda_vp9_amd.pipeline as pipeline  # noqa: E402
-import cuda_vp9_amd.workload as workload  # noqa: E402
+import workload  # noqa: E402
 ctx = pkg.Context(0)
 wl = workload.make_frame_workload(args.width, args.height, seed=1440)
 job = pipeline.FrameJob(ctx, wl)

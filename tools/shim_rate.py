@@ -9,7 +9,7 @@ import numpy as np
 import __graft_entry__ as g
 hip = g.load_pkg()
 import blockgen
-import cuda_vp9_amd.workload as workload
+import workload
 W, H, bd = 2560, 1440, int(sys.argv[1]) if len(sys.argv) > 1 else 8
 coefficient_mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(7)
