@@ -3,12 +3,14 @@
  * See include/vp9hip_pack.h for the list of reference functions each part restates; file:line
  * citations below are relative to /root/reference/libvpx/.
  */
+#define _POSIX_C_SOURCE 200809L
 #include "vp9hip_pack.h"
 
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ---- block geometry (vp9/common/vp9_common_data.c: num_4x4_blocks_{wide,high}_lookup) ------- */
 static const uint8_t kW4[13] = { 1, 1, 2, 2, 2, 4, 4, 4, 8, 8, 8, 16, 16 };
@@ -23,24 +25,36 @@ typedef struct {
   size_t cap; /* bytes */
 } vec;
 
+struct pk_pool;
+struct pk_job_s;
+
 struct vp9hip_packer {
   char err[256];
   vp9hip_alloc_fn alloc;
   vp9hip_free_fn release;
   void *alloc_user;
+  struct pk_pool *pool;
+  struct pk_job_s *job;
+  int threads;
+  int32_t own_base;    /* see the intra dependency maps */
+  size_t own_cells[3];
   vec inter, inter_sorted, txb, txb_sorted, intra, intra_isl, intra_big, islands, wave_off, big_wave_start;
   vec level, parent, comp_id, comp_size, order_a, order_b, count;
   vec lvl_map[3], own_map[3];
   vec lfm, lf_raw, rows_expected, lf_skip;
 };
 
-/* Contents are kept when a vector grows (some are appended to across passes). */
+/* Contents are kept when a vector grows (some are appended to across passes).  Only the vectors the
+ * frame driver copies to the device (vec_is_output) come from the caller's allocator — page-locked
+ * memory is expensive to obtain, so those also start large and grow with headroom. */
+static int vec_is_output(const vp9hip_packer *pk, const vec *v);
 static int vec_reserve_pk(vp9hip_packer *pk, vec *v, size_t bytes) {
   if (bytes <= v->cap) return 0;
-  size_t ncap = v->cap ? v->cap : 4096;
-  while (ncap < bytes) ncap *= 2;
+  const int out = pk->alloc && vec_is_output(pk, v);
+  size_t ncap = v->cap ? v->cap : (out ? (size_t)1 << 16 : 4096);
+  while (ncap < bytes + (out ? bytes >> 1 : 0)) ncap *= 2;
   void *np;
-  if (pk->alloc) {
+  if (out) {
     np = pk->alloc(pk->alloc_user, ncap);
     if (!np) return -1;
     if (v->p) {
@@ -57,6 +71,11 @@ static int vec_reserve_pk(vp9hip_packer *pk, vec *v, size_t bytes) {
 }
 #define vec_reserve(v, bytes) vec_reserve_pk(pk, (v), (bytes))
 
+static int vec_is_output(const vp9hip_packer *pk, const vec *v) {
+  return v == &pk->inter_sorted || v == &pk->txb_sorted || v == &pk->intra_isl || v == &pk->intra_big || v == &pk->islands ||
+         v == &pk->wave_off || v == &pk->lfm || v == &pk->rows_expected;
+}
+
 int vp9hip_packer_create_ex(vp9hip_packer **out, vp9hip_alloc_fn alloc, vp9hip_free_fn release, void *user) {
   if (!out || (alloc != NULL) != (release != NULL)) return VP9HIP_EINVAL;
   *out = (vp9hip_packer *)calloc(1, sizeof(vp9hip_packer));
@@ -69,8 +88,12 @@ int vp9hip_packer_create_ex(vp9hip_packer **out, vp9hip_alloc_fn alloc, vp9hip_f
 
 int vp9hip_packer_create(vp9hip_packer **out) { return vp9hip_packer_create_ex(out, NULL, NULL, NULL); }
 
+static void pk_pool_destroy(struct pk_pool *pl);
+
 void vp9hip_packer_destroy(vp9hip_packer *pk) {
   if (!pk) return;
+  pk_pool_destroy(pk->pool);
+  free(pk->job);
   vec *all[] = { &pk->inter,    &pk->inter_sorted, &pk->txb,       &pk->txb_sorted, &pk->intra,    &pk->intra_isl,
                  &pk->intra_big, &pk->islands,     &pk->wave_off,  &pk->big_wave_start, &pk->level, &pk->parent,
                  &pk->comp_id,  &pk->comp_size,    &pk->order_a,   &pk->order_b,    &pk->count,    &pk->lvl_map[0],
@@ -78,7 +101,7 @@ void vp9hip_packer_destroy(vp9hip_packer *pk) {
                  &pk->lf_raw,   &pk->rows_expected, &pk->lf_skip };
   for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) {
     if (!all[i]->p) continue;
-    if (pk->release) pk->release(pk->alloc_user, all[i]->p);
+    if (pk->release && vec_is_output(pk, all[i])) pk->release(pk->alloc_user, all[i]->p);
     else free(all[i]->p);
   }
   free(pk);
@@ -368,52 +391,185 @@ static int uf_find(int32_t *parent, int a) {
   return a;
 }
 
-/* ---- the frame packer ---------------------------------------------------------------------- */
 
-int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9hip_block *blocks, int n_blocks,
-                      const vp9hip_coeff_layout *coeffs, vp9hip_packed *out) {
-  if (!pk) return VP9HIP_EINVAL;
-  if (!P || !out || n_blocks < 0 || (n_blocks && !blocks)) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: null argument");
-  if (P->width <= 0 || P->height <= 0 || P->width > 16384 || P->height > 16384)
-    PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: bad frame size %dx%d", P->width, P->height);
-  if (P->ss_x != P->ss_y || (P->ss_x != 0 && P->ss_x != 1))
-    PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: only 4:2:0 and 4:4:4 are supported (ss %d,%d)", P->ss_x, P->ss_y);
-  const int ss = P->ss_x;
-  const int aw = (P->width + 7) & ~7, ah = (P->height + 7) & ~7;
-  const int mi_cols = aw >> 3, mi_rows = ah >> 3;
-  const int sb_cols = (mi_cols + 7) >> 3, sb_rows = (mi_rows + 7) >> 3;
-  const int paw[3] = { aw, aw >> ss, aw >> ss }, pah[3] = { ah, ah >> ss, ah >> ss };
-  memset(out, 0, sizeof(*out));
+static double pk_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e6 + 1e-3 * (double)ts.tv_nsec;
+}
 
-  scale_factors sf[3];
-  memset(sf, 0, sizeof(sf));
-  int sf_valid[3] = { 0, 0, 0 };
-  for (int r = 0; r < 3; ++r)
-    if (P->ref_width[r] > 0 && P->ref_height[r] > 0)
-      sf_valid[r] = setup_scale(&sf[r], P->ref_width[r], P->ref_height[r], P->width, P->height) == 0;
+/* ---- a small fork/join pool (the packer's passes over the block list are split into ranges of whole
+ * superblocks; SURVEY §8f-2/f-3: the host side of the path must not be the bottleneck) ------------- */
+#include <pthread.h>
+#include <unistd.h>
 
-  /* ---- pass 0: sizes ---------------------------------------------------------------------- */
-  size_t n_inter = 0, n_tx = 0;
-  int64_t coeff_count[3] = { 0, 0, 0 };
-  for (int i = 0; i < n_blocks; ++i) {
-    const vp9hip_block *b = &blocks[i];
-    if (b->sb_type > 12 || b->tx_size > 3 || b->mi_row < 0 || b->mi_col < 0 || b->mi_row >= mi_rows ||
-        b->mi_col >= mi_cols)
-      PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d out of range (sb_type %d tx %d at mi %d,%d)", i, b->sb_type,
-              b->tx_size, b->mi_row, b->mi_col);
+#define PK_MAX_THREADS 16
+
+typedef void (*pk_fn)(void *arg, int tid);
+
+struct pk_pool {
+  int n; /* workers besides the caller */
+  pthread_t th[PK_MAX_THREADS];
+  pthread_mutex_t mu;
+  pthread_cond_t cv_go, cv_done;
+  unsigned gen;
+  int pending, stop;
+  pk_fn fn;
+  void *arg;
+  int ids[PK_MAX_THREADS];
+  struct pk_pool *self[PK_MAX_THREADS];
+};
+
+typedef struct {
+  struct pk_pool *pool;
+  int tid;
+} pk_worker_arg;
+
+static void *pk_worker(void *argp) {
+  pk_worker_arg *wa = (pk_worker_arg *)argp;
+  struct pk_pool *pl = wa->pool;
+  const int tid = wa->tid;
+  unsigned seen = 0;
+  free(wa);
+  for (;;) {
+    pthread_mutex_lock(&pl->mu);
+    while (pl->gen == seen && !pl->stop) pthread_cond_wait(&pl->cv_go, &pl->mu);
+    if (pl->stop) {
+      pthread_mutex_unlock(&pl->mu);
+      return NULL;
+    }
+    seen = pl->gen;
+    pk_fn fn = pl->fn;
+    void *arg = pl->arg;
+    pthread_mutex_unlock(&pl->mu);
+    fn(arg, tid);
+    pthread_mutex_lock(&pl->mu);
+    if (--pl->pending == 0) pthread_cond_signal(&pl->cv_done);
+    pthread_mutex_unlock(&pl->mu);
+  }
+}
+
+static struct pk_pool *pk_pool_create(int workers) {
+  struct pk_pool *pl = (struct pk_pool *)calloc(1, sizeof(*pl));
+  if (!pl) return NULL;
+  pthread_mutex_init(&pl->mu, NULL);
+  pthread_cond_init(&pl->cv_go, NULL);
+  pthread_cond_init(&pl->cv_done, NULL);
+  for (int i = 0; i < workers && i < PK_MAX_THREADS - 1; ++i) {
+    pk_worker_arg *wa = (pk_worker_arg *)malloc(sizeof(*wa));
+    if (!wa) break;
+    wa->pool = pl;
+    wa->tid = i + 1;
+    if (pthread_create(&pl->th[pl->n], NULL, pk_worker, wa)) {
+      free(wa);
+      break;
+    }
+    ++pl->n;
+  }
+  return pl;
+}
+
+static void pk_pool_destroy(struct pk_pool *pl) {
+  if (!pl) return;
+  pthread_mutex_lock(&pl->mu);
+  pl->stop = 1;
+  pthread_cond_broadcast(&pl->cv_go);
+  pthread_mutex_unlock(&pl->mu);
+  for (int i = 0; i < pl->n; ++i) pthread_join(pl->th[i], NULL);
+  pthread_mutex_destroy(&pl->mu);
+  pthread_cond_destroy(&pl->cv_go);
+  pthread_cond_destroy(&pl->cv_done);
+  free(pl);
+}
+
+/* fn(arg, tid) for tid 0..threads-1; the caller is tid 0 */
+static void pk_parallel(struct pk_pool *pl, int threads, pk_fn fn, void *arg) {
+  if (!pl || threads <= 1) {
+    for (int t = 0; t < threads; ++t) fn(arg, t);
+    return;
+  }
+  /* workers beyond `threads` return at once (their range is empty) */
+  pthread_mutex_lock(&pl->mu);
+  pl->fn = fn;
+  pl->arg = arg;
+  pl->pending = pl->n;
+  ++pl->gen;
+  pthread_cond_broadcast(&pl->cv_go);
+  pthread_mutex_unlock(&pl->mu);
+  fn(arg, 0);
+  pthread_mutex_lock(&pl->mu);
+  while (pl->pending) pthread_cond_wait(&pl->cv_done, &pl->mu);
+  pthread_mutex_unlock(&pl->mu);
+}
+
+/* ---- the per-range passes -------------------------------------------------------------------- */
+typedef struct pk_job_s {
+  /* inputs */
+  vp9hip_packer *pk;
+  const vp9hip_frame_params *P;
+  const vp9hip_block *blocks;
+  const vp9hip_coeff_layout *coeffs;
+  int n_blocks, threads, ss, mi_cols, mi_rows, sb_cols, sb_rows, have_eobs;
+  int range[PK_MAX_THREADS + 1]; /* block ranges, split at superblock boundaries */
+  const void *sf;                /* scale_factors[3] */
+  const int *sf_valid;
+  /* per-range results of pass 0 */
+  int32_t n_inter[PK_MAX_THREADS], n_tx_ub[PK_MAX_THREADS], n_intra[PK_MAX_THREADS];
+  int64_t coeff[PK_MAX_THREADS][3];
+  /* offsets handed to pass 1 */
+  int32_t inter_off[PK_MAX_THREADS], txb_off[PK_MAX_THREADS], intra_off[PK_MAX_THREADS];
+  int64_t run_off[PK_MAX_THREADS][3];
+  int64_t coeff_base[3];
+  /* per-range results of pass 1 */
+  int32_t n_txb[PK_MAX_THREADS], hist_inter[PK_MAX_THREADS][6], hist_txb[PK_MAX_THREADS][4];
+  uint32_t refs_used[PK_MAX_THREADS];
+  /* sorted positions handed to the scatter */
+  int32_t pos_inter[PK_MAX_THREADS][6], pos_txb[PK_MAX_THREADS][4];
+  /* arrays */
+  vp9hip_inter_task *it, *it_sorted;
+  vp9hip_txb *tb, *tb_sorted;
+  vp9hip_intra_task *ia;
+  int32_t *key;
+  uint8_t *lf_skip;
+  void *lf_raw; /* lfm_raw[sb_rows * sb_cols] or NULL */
+  vp9hip_lfm *lfm;
+  /* errors */
+  int err[PK_MAX_THREADS];
+  char errmsg[PK_MAX_THREADS][160];
+} pk_job;
+
+#define JOB_FAIL(j, tid, ...)                                        \
+  do {                                                               \
+    (j)->err[tid] = VP9HIP_EINVAL;                                   \
+    snprintf((j)->errmsg[tid], sizeof((j)->errmsg[tid]), __VA_ARGS__); \
+    return;                                                          \
+  } while (0)
+
+/* pass 0: validate, count (exact but for the residual records, whose number depends on the eobs: upper bound) */
+static void pk_pass0(void *argp, int tid) {
+  pk_job *j = (pk_job *)argp;
+  if (tid >= j->threads) return;
+  const int ss = j->ss, mi_cols = j->mi_cols, mi_rows = j->mi_rows;
+  int32_t n_inter = 0, n_tx_ub = 0, n_intra = 0;
+  int64_t cc[3] = { 0, 0, 0 };
+  for (int i = j->range[tid]; i < j->range[tid + 1]; ++i) {
+    const vp9hip_block *b = &j->blocks[i];
+    if (b->sb_type > 12 || b->tx_size > 3 || b->mi_row < 0 || b->mi_col < 0 || b->mi_row >= mi_rows || b->mi_col >= mi_cols)
+      JOB_FAIL(j, tid, "vp9hip_pack_frame: block %d out of range (sb_type %d tx %d at mi %d,%d)", i, b->sb_type, b->tx_size,
+               b->mi_row, b->mi_col);
     const int bw8 = kW4[b->sb_type] > 1 ? kW4[b->sb_type] >> 1 : 1, bh8 = kH4[b->sb_type] > 1 ? kH4[b->sb_type] >> 1 : 1;
     const int to_right = (mi_cols - bw8 - b->mi_col) * 64, to_bottom = (mi_rows - bh8 - b->mi_row) * 64;
     const int inter = b->ref_frame[0] > 0;
     if (inter) {
       for (int r = 0; r < 1 + (b->ref_frame[1] > 0); ++r) {
         const int k = b->ref_frame[r] - 1;
-        if (k < 0 || k > 2 || !sf_valid[k])
-          PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d uses reference %d which has no valid size", i, k + 1);
+        if (k < 0 || k > 2 || !j->sf_valid[k])
+          JOB_FAIL(j, tid, "vp9hip_pack_frame: block %d uses reference %d which has no valid size", i, k + 1);
       }
-      if (b->interp_filter > 3) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d bad interp_filter", i);
-      n_inter += b->sb_type < 3 ? (size_t)(4 + 2 * (ss ? 1 : 4)) : 3;
+      if (b->interp_filter > 3) JOB_FAIL(j, tid, "vp9hip_pack_frame: block %d bad interp_filter", i);
+      n_inter += b->sb_type < 3 ? (4 + 2 * (ss ? 1 : 4)) : 3;
     } else if (b->mode > 9 || b->uv_mode > 9) {
-      PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d bad intra mode", i);
+      JOB_FAIL(j, tid, "vp9hip_pack_frame: block %d bad intra mode", i);
     }
     for (int p = 0; p < 3; ++p) {
       const int s = p ? ss : 0;
@@ -421,40 +577,51 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
       const int tx = p ? uv_tx_size(b->sb_type, b->tx_size, ss) : b->tx_size;
       const int mw = n4w + (to_right >= 0 ? 0 : to_right >> (5 + s)), mh = n4h + (to_bottom >= 0 ? 0 : to_bottom >> (5 + s));
       const int step = 1 << tx;
-      const int cnt = ((mw + step - 1) / step) * ((mh + step - 1) / step);
       if (mw <= 0 || mh <= 0) continue;
-      if (!inter || !b->skip) n_tx += (size_t)cnt;
-      if (!b->skip) coeff_count[p] += (int64_t)cnt * (16 << (2 * tx));
+      const int cnt = ((mw + step - 1) / step) * ((mh + step - 1) / step);
+      if (!inter) n_intra += cnt;
+      else if (!b->skip) n_tx_ub += cnt;
+      if (!b->skip) cc[p] += (int64_t)cnt * (16 << (2 * tx));
     }
   }
-  out->coeff_base[0] = 0;
-  out->coeff_base[1] = coeff_count[0];
-  out->coeff_base[2] = coeff_count[0] + coeff_count[1];
-  out->coeff_total = coeff_count[0] + coeff_count[1] + coeff_count[2];
-  memcpy(out->coeff_count, coeff_count, sizeof(coeff_count));
-  if (out->coeff_total > (int64_t)UINT32_MAX) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: too many coefficients");
+  j->n_inter[tid] = n_inter;
+  j->n_tx_ub[tid] = n_tx_ub;
+  j->n_intra[tid] = n_intra;
+  memcpy(j->coeff[tid], cc, sizeof(cc));
+}
 
-  if (vec_reserve(&pk->inter, (n_inter + 1) * sizeof(vp9hip_inter_task)) ||
-      vec_reserve(&pk->inter_sorted, (n_inter + 1) * sizeof(vp9hip_inter_task)) ||
-      vec_reserve(&pk->txb, (n_tx + 1) * sizeof(vp9hip_txb)) || vec_reserve(&pk->txb_sorted, (n_tx + 1) * sizeof(vp9hip_txb)) ||
-      vec_reserve(&pk->intra, (n_tx + 1) * sizeof(vp9hip_intra_task)) ||
-      vec_reserve(&pk->order_a, (n_tx + n_inter + 1) * sizeof(int32_t)) || vec_reserve(&pk->lf_skip, (size_t)n_blocks + 1))
-    PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
-  /* the skip flag the loop filter sees: libvpx turns an inter block of 8x8 or more whose transform blocks
-   * all have eob 0 into a skipped one before the masks are built (`if (!less8x8 && eobtotal == 0)
-   * mi->skip = 1`, vp9/decoder/vp9_decodeframe.c:1195; stock libvpx builds the masks after it) */
-  uint8_t *lf_skip = (uint8_t *)pk->lf_skip.p;
-  const int have_eobs = coeffs && coeffs->eob[0];
-  vp9hip_inter_task *it = (vp9hip_inter_task *)pk->inter.p;
-  vp9hip_txb *tb = (vp9hip_txb *)pk->txb.p;
-  vp9hip_intra_task *ia = (vp9hip_intra_task *)pk->intra.p;
-  int32_t *key = (int32_t *)pk->order_a.p;
-  int ni = 0, nt = 0, na = 0;
-  int64_t run[3] = { 0, 0, 0 };
+/* pass 1: the records of a range of blocks, in decode order, into the range's slice of the unsorted
+ * arrays; class histograms for the scatter; loop-filter masks of the range's superblocks */
+static void pk_pass1(void *argp, int tid) {
+  pk_job *j = (pk_job *)argp;
+  if (tid >= j->threads) return;
+  const vp9hip_frame_params *P = j->P;
+  const vp9hip_block *blocks = j->blocks;
+  const vp9hip_coeff_layout *coeffs = j->coeffs;
+  const scale_factors *sf = (const scale_factors *)j->sf;
+  const int ss = j->ss, mi_cols = j->mi_cols, mi_rows = j->mi_rows, have_eobs = j->have_eobs;
+  vp9hip_inter_task *it = j->it;
+  vp9hip_txb *tb = j->tb;
+  vp9hip_intra_task *ia = j->ia;
+  int32_t *key = j->key;
+  uint8_t *lf_skip = j->lf_skip;
+  lfm_raw *raw = (lfm_raw *)j->lf_raw;
+  int ni = j->inter_off[tid], nt = j->txb_off[tid], na = j->intra_off[tid];
+  int64_t run[3] = { j->run_off[tid][0], j->run_off[tid][1], j->run_off[tid][2] };
   uint32_t refs_used = 0;
-
-  /* ---- pass 1: records in decode order ------------------------------------------------------ */
-  for (int i = 0; i < n_blocks; ++i) {
+  int32_t hist_inter[6] = { 0, 0, 0, 0, 0, 0 }, hist_txb[4] = { 0, 0, 0, 0 }; /* local: no shared cache lines */
+  if (raw && j->range[tid] < j->range[tid + 1]) {
+    /* the range is a run of whole superblocks in decode order: clear exactly the records it owns */
+    int prev = -1;
+    for (int i = j->range[tid]; i < j->range[tid + 1]; ++i) {
+      const int sb = (blocks[i].mi_row >> 3) * j->sb_cols + (blocks[i].mi_col >> 3);
+      if (sb != prev) {
+        memset(&raw[sb], 0, sizeof(lfm_raw));
+        prev = sb;
+      }
+    }
+  }
+  for (int i = j->range[tid]; i < j->range[tid + 1]; ++i) {
     const vp9hip_block *b = &blocks[i];
     const int bw8 = kW4[b->sb_type] > 1 ? kW4[b->sb_type] >> 1 : 1, bh8 = kH4[b->sb_type] > 1 ? kH4[b->sb_type] >> 1 : 1;
     /* set_mi_row_col (vp9/common/vp9_onyxc_int.h): distances to the frame edges in 1/8 sample */
@@ -530,6 +697,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
               int cls = 5;
               if (!any_scaled) cls = t->w == 4 ? 0 : t->w == 8 ? 1 : t->w == 16 ? 2 : t->w == 32 ? 3 : 4;
               key[ni] = cls;
+              ++hist_inter[cls];
             }
             ++ni;
           }
@@ -551,18 +719,19 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
           int eob = 0;
           uint32_t off = 0;
           if (!b->skip) {
-            off = (uint32_t)(out->coeff_base[p] + run[p]);
+            off = (uint32_t)(j->coeff_base[p] + run[p]);
             run[p] += nn;
             if (coeffs && coeffs->eob[p])
               eob = coeffs->eob[p][(size_t)y * coeffs->eob_stride[p] + x];
             else if (P->assume_coded)
               eob = 1;
-            if (eob < 0 || eob > nn) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: bad eob %d (block %d plane %d)", eob, i, p);
+            if (eob < 0 || eob > nn) JOB_FAIL(j, tid, "vp9hip_pack_frame: bad eob %d (block %d plane %d)", eob, i, p);
             eobtotal += eob;
           }
           if (inter) {
             if (eob > 0) {
               vp9hip_txb *r = &tb[nt++];
+              ++hist_txb[tx];
               memset(r, 0, sizeof(*r));
               r->coeff_off = off;
               r->x = (uint16_t)x;
@@ -576,7 +745,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
             vp9hip_intra_task *r = &ia[na++];
             int mode = p ? b->uv_mode : b->mode;
             if (sub8 && p == 0) mode = b->sub_mode[(row << 1) + col];
-            if (mode > 9) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: block %d bad intra sub-mode", i);
+            if (mode > 9) JOB_FAIL(j, tid, "vp9hip_pack_frame: block %d bad intra sub-mode", i);
             memset(r, 0, sizeof(*r));
             r->coeff_off = off;
             r->x = (uint16_t)x;
@@ -592,26 +761,214 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
         }
     }
     lf_skip[i] = (uint8_t)(b->skip || (have_eobs && inter && !sub8 && eobtotal == 0));
+    if (raw) lf_build_mask(&raw[(size_t)(b->mi_row >> 3) * j->sb_cols + (b->mi_col >> 3)], b, lf_skip[i]);
   }
-  if (run[0] != coeff_count[0] || run[1] != coeff_count[1] || run[2] != coeff_count[2])
-    PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: internal coefficient count mismatch");
 
-  /* ---- inter tasks by class, residual records by size --------------------------------------- */
-  if (vec_reserve(&pk->count, sizeof(int32_t) * 16)) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
-  int32_t *cnt = (int32_t *)pk->count.p;
-  counting_sort(it, pk->inter_sorted.p, sizeof(vp9hip_inter_task), key, ni, 6, cnt);
-  for (int k = 0; k < 6; ++k) out->inter_class_count[k] = 0;
-  for (int i = 0; i < ni; ++i) ++out->inter_class_count[key[i]];
+  j->n_txb[tid] = nt - j->txb_off[tid];
+  j->refs_used[tid] = refs_used;
+  memcpy(j->hist_inter[tid], hist_inter, sizeof(hist_inter));
+  memcpy(j->hist_txb[tid], hist_txb, sizeof(hist_txb));
+  if (ni != j->inter_off[tid] + j->n_inter[tid] || na != j->intra_off[tid] + j->n_intra[tid] ||
+      run[0] != j->run_off[tid][0] + j->coeff[tid][0] || run[1] != j->run_off[tid][1] + j->coeff[tid][1] ||
+      run[2] != j->run_off[tid][2] + j->coeff[tid][2])
+    JOB_FAIL(j, tid, "vp9hip_pack_frame: internal count mismatch");
+  if (raw) {
+    int prev = -1;
+    for (int i = j->range[tid]; i < j->range[tid + 1]; ++i) {
+      const int r = blocks[i].mi_row >> 3, c = blocks[i].mi_col >> 3, sb = r * j->sb_cols + c;
+      if (sb != prev) {
+        lf_adjust_mask(&raw[sb], &j->lfm[sb], r * 8, c * 8, mi_rows, mi_cols);
+        prev = sb;
+      }
+    }
+  }
+}
+
+/* scatter: every range moves its records to their final, class-sorted places (a stable counting sort
+ * whose counting was done in pass 1) */
+static void pk_scatter(void *argp, int tid) {
+  pk_job *j = (pk_job *)argp;
+  if (tid >= j->threads) return;
+  int32_t pos[6];
+  memcpy(pos, j->pos_inter[tid], sizeof(pos));
+  for (int i = j->inter_off[tid], e = i + j->n_inter[tid]; i < e; ++i) j->it_sorted[pos[j->key[i]]++] = j->it[i];
+  memcpy(pos, j->pos_txb[tid], sizeof(int32_t) * 4);
+  for (int i = j->txb_off[tid], e = i + j->n_txb[tid]; i < e; ++i) j->tb_sorted[pos[j->tb[i].tx_size]++] = j->tb[i];
+}
+
+/* ---- the frame packer ---------------------------------------------------------------------- */
+#define PK_MARK(name)                                                      \
+  do {                                                                     \
+    if (trace) {                                                           \
+      const double n_ = pk_now();                                          \
+      fprintf(stderr, "  pack: %-28s %8.1f us\n", name, n_ - t_mark);       \
+      t_mark = n_;                                                         \
+    }                                                                      \
+  } while (0)
+
+int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9hip_block *blocks, int n_blocks,
+                      const vp9hip_coeff_layout *coeffs, vp9hip_packed *out) {
+  if (!pk) return VP9HIP_EINVAL;
+  if (!P || !out || n_blocks < 0 || (n_blocks && !blocks)) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: null argument");
+  if (P->width <= 0 || P->height <= 0 || P->width > 16384 || P->height > 16384)
+    PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: bad frame size %dx%d", P->width, P->height);
+  if (P->ss_x != P->ss_y || (P->ss_x != 0 && P->ss_x != 1))
+    PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: only 4:2:0 and 4:4:4 are supported (ss %d,%d)", P->ss_x, P->ss_y);
+  const int trace = getenv("VP9HIP_PACK_TRACE") != NULL;
+  double t_mark = trace ? pk_now() : 0.0;
+  const int ss = P->ss_x;
+  const int aw = (P->width + 7) & ~7, ah = (P->height + 7) & ~7;
+  const int mi_cols = aw >> 3, mi_rows = ah >> 3;
+  const int sb_cols = (mi_cols + 7) >> 3, sb_rows = (mi_rows + 7) >> 3;
+  const int paw[3] = { aw, aw >> ss, aw >> ss }, pah[3] = { ah, ah >> ss, ah >> ss };
+  memset(out, 0, sizeof(*out));
+
+  scale_factors sf[3];
+  memset(sf, 0, sizeof(sf));
+  int sf_valid[3] = { 0, 0, 0 };
+  for (int r = 0; r < 3; ++r)
+    if (P->ref_width[r] > 0 && P->ref_height[r] > 0)
+      sf_valid[r] = setup_scale(&sf[r], P->ref_width[r], P->ref_height[r], P->width, P->height) == 0;
+
+  /* ---- ranges of whole superblocks, one per thread ------------------------------------------------ */
+  pk_job *j = pk->job;
+  if (!j) {
+    j = pk->job = (pk_job *)calloc(1, sizeof(pk_job));
+    if (!j) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+  }
+  int threads = pk->threads;
+  if (threads <= 0) {
+    const char *e = getenv("VP9HIP_PACK_THREADS");
+    long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    threads = e ? atoi(e) : (nc >= 16 ? 8 : nc >= 8 ? 4 : nc >= 4 ? 2 : 1);
+    if (threads < 1) threads = 1;
+    if (threads > PK_MAX_THREADS) threads = PK_MAX_THREADS;
+    pk->threads = threads;
+  }
+  if (n_blocks < 2048) threads = 1; /* not worth a fork/join */
+  if (threads > 1 && !pk->pool) pk->pool = pk_pool_create(pk->threads - 1);
+  if (threads > 1 && (!pk->pool || pk->pool->n + 1 < threads)) threads = pk->pool ? pk->pool->n + 1 : 1;
+  j->pk = pk;
+  j->P = P;
+  j->blocks = blocks;
+  j->coeffs = coeffs;
+  j->n_blocks = n_blocks;
+  j->threads = threads;
+  j->ss = ss;
+  j->mi_cols = mi_cols;
+  j->mi_rows = mi_rows;
+  j->sb_cols = sb_cols;
+  j->sb_rows = sb_rows;
+  j->have_eobs = coeffs && coeffs->eob[0];
+  j->sf = sf;
+  j->sf_valid = sf_valid;
+  memset(j->err, 0, sizeof(j->err));
+  j->range[0] = 0;
+  for (int t = 1; t < threads; ++t) {
+    int i = (int)((int64_t)n_blocks * t / threads);
+    if (i < j->range[t - 1]) i = j->range[t - 1];
+    /* forward to the first block of the next superblock */
+    while (i > 0 && i < n_blocks && (blocks[i].mi_row >> 3) == (blocks[i - 1].mi_row >> 3) &&
+           (blocks[i].mi_col >> 3) == (blocks[i - 1].mi_col >> 3))
+      ++i;
+    j->range[t] = i;
+  }
+  j->range[threads] = n_blocks;
+
+  /* ---- pass 0: sizes ---------------------------------------------------------------------- */
+  pk_parallel(pk->pool, threads, pk_pass0, j);
+  for (int t = 0; t < threads; ++t)
+    if (j->err[t]) PK_FAIL(pk, j->err[t], "%s", j->errmsg[t]);
+  size_t n_inter = 0, n_tx = 0, n_intra_total = 0;
+  int64_t coeff_count[3] = { 0, 0, 0 };
+  for (int t = 0; t < threads; ++t) {
+    j->inter_off[t] = (int32_t)n_inter;
+    j->txb_off[t] = (int32_t)n_tx;
+    j->intra_off[t] = (int32_t)n_intra_total;
+    for (int p = 0; p < 3; ++p) {
+      j->run_off[t][p] = coeff_count[p];
+      coeff_count[p] += j->coeff[t][p];
+    }
+    n_inter += (size_t)j->n_inter[t];
+    n_tx += (size_t)j->n_tx_ub[t];
+    n_intra_total += (size_t)j->n_intra[t];
+  }
+  PK_MARK("pass 0 (sizes)");
+  out->coeff_base[0] = 0;
+  out->coeff_base[1] = coeff_count[0];
+  out->coeff_base[2] = coeff_count[0] + coeff_count[1];
+  out->coeff_total = coeff_count[0] + coeff_count[1] + coeff_count[2];
+  memcpy(out->coeff_count, coeff_count, sizeof(coeff_count));
+  if (out->coeff_total > (int64_t)UINT32_MAX) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: too many coefficients");
+  memcpy(j->coeff_base, out->coeff_base, sizeof(j->coeff_base));
+
+  const size_t n_sb = (size_t)sb_rows * sb_cols;
+  if (vec_reserve(&pk->inter, (n_inter + 1) * sizeof(vp9hip_inter_task)) ||
+      vec_reserve(&pk->inter_sorted, (n_inter + 1) * sizeof(vp9hip_inter_task)) ||
+      vec_reserve(&pk->txb, (n_tx + 1) * sizeof(vp9hip_txb)) || vec_reserve(&pk->txb_sorted, (n_tx + 1) * sizeof(vp9hip_txb)) ||
+      vec_reserve(&pk->intra, (n_intra_total + 1) * sizeof(vp9hip_intra_task)) ||
+      vec_reserve(&pk->order_a, (n_tx + n_inter + n_intra_total + 1) * sizeof(int32_t)) ||
+      vec_reserve(&pk->lf_skip, (size_t)n_blocks + 1) ||
+      (P->build_lf_masks && (vec_reserve(&pk->lf_raw, n_sb * sizeof(lfm_raw)) || vec_reserve(&pk->lfm, n_sb * sizeof(vp9hip_lfm)))))
+    PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+  vp9hip_inter_task *it = (vp9hip_inter_task *)pk->inter.p;
+  vp9hip_txb *tb = (vp9hip_txb *)pk->txb.p;
+  vp9hip_intra_task *ia = (vp9hip_intra_task *)pk->intra.p;
+  int32_t *key = (int32_t *)pk->order_a.p;
+  j->it = it;
+  j->it_sorted = (vp9hip_inter_task *)pk->inter_sorted.p;
+  j->tb = tb;
+  j->tb_sorted = (vp9hip_txb *)pk->txb_sorted.p;
+  j->ia = ia;
+  j->key = key;
+  j->lf_skip = (uint8_t *)pk->lf_skip.p;
+  j->lf_raw = P->build_lf_masks ? pk->lf_raw.p : NULL;
+  j->lfm = P->build_lf_masks ? (vp9hip_lfm *)pk->lfm.p : NULL;
+  if (P->build_lf_masks) {
+    /* superblocks no block list entry starts in (none in a well-formed frame) still get a defined record */
+    if ((size_t)n_blocks < n_sb) memset(pk->lfm.p, 0, n_sb * sizeof(vp9hip_lfm));
+  }
+
+  /* ---- pass 1: records in decode order, masks --------------------------------------------------- */
+  pk_parallel(pk->pool, threads, pk_pass1, j);
+  for (int t = 0; t < threads; ++t)
+    if (j->err[t]) PK_FAIL(pk, j->err[t], "%s", j->errmsg[t]);
+  PK_MARK("pass 1 (records + masks)");
+
+  /* ---- inter tasks by class, residual records by size: positions, then a parallel scatter ------- */
+  const int ni = (int)n_inter, na = (int)n_intra_total;
+  int nt = 0;
+  uint32_t refs_used = 0;
+  {
+    int32_t run_i = 0, run_t = 0;
+    for (int k = 0; k < 6; ++k) {
+      out->inter_class_count[k] = 0;
+      for (int t = 0; t < threads; ++t) {
+        j->pos_inter[t][k] = run_i;
+        run_i += j->hist_inter[t][k];
+        out->inter_class_count[k] += j->hist_inter[t][k];
+      }
+    }
+    for (int k = 0; k < 4; ++k) {
+      out->txb_size_count[k] = 0;
+      for (int t = 0; t < threads; ++t) {
+        j->pos_txb[t][k] = run_t;
+        run_t += j->hist_txb[t][k];
+        out->txb_size_count[k] += j->hist_txb[t][k];
+      }
+    }
+    nt = run_t;
+    for (int t = 0; t < threads; ++t) refs_used |= j->refs_used[t];
+  }
+  pk_parallel(pk->pool, threads, pk_scatter, j);
   out->inter = (const vp9hip_inter_task *)pk->inter_sorted.p;
   out->n_inter = ni;
-  for (int i = 0; i < nt; ++i) key[i] = tb[i].tx_size;
-  counting_sort(tb, pk->txb_sorted.p, sizeof(vp9hip_txb), key, nt, 4, cnt);
-  for (int k = 0; k < 4; ++k) out->txb_size_count[k] = 0;
-  for (int i = 0; i < nt; ++i) ++out->txb_size_count[key[i]];
   out->txb = (const vp9hip_txb *)pk->txb_sorted.p;
   out->n_txb = nt;
   out->refs_used = refs_used;
-
+  if (vec_reserve(&pk->count, sizeof(int32_t) * 16)) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+  int32_t *cnt = (int32_t *)pk->count.p;
+  PK_MARK("sort inter + txb");
   /* ---- intra: dependency levels + connected components --------------------------------------- */
   out->intra_decode_order = ia;
   out->n_intra = na;
@@ -624,29 +981,38 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
   int32_t *lv = (int32_t *)pk->level.p, *parent = (int32_t *)pk->parent.p, *comp = (int32_t *)pk->comp_id.p;
   int max_level = 0;
   if (na) {
-    int32_t *lmap[3], *omap[3];
+    /* own_map[p][cell] = base + index of the last intra task that covered the 4x4 cell; values below
+     * `base` are leftovers of earlier frames (the maps are not cleared per frame) */
+    int32_t *omap[3];
+    int reset = pk->own_base <= 0 || pk->own_base > INT32_MAX - (na + 2);
     for (int p = 0; p < 3; ++p) {
       const size_t cells = (size_t)(paw[p] >> 2) * (size_t)(pah[p] >> 2);
-      if (vec_reserve(&pk->lvl_map[p], cells * sizeof(int32_t)) || vec_reserve(&pk->own_map[p], cells * sizeof(int32_t)))
-        PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
-      lmap[p] = (int32_t *)pk->lvl_map[p].p;
+      if (cells != pk->own_cells[p]) reset = 1;
+      if (vec_reserve(&pk->own_map[p], cells * sizeof(int32_t))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
       omap[p] = (int32_t *)pk->own_map[p].p;
-      memset(lmap[p], 0, cells * sizeof(int32_t));
-      memset(omap[p], 0xff, cells * sizeof(int32_t));
     }
+    if (reset) {
+      for (int p = 0; p < 3; ++p) {
+        pk->own_cells[p] = (size_t)(paw[p] >> 2) * (size_t)(pah[p] >> 2);
+        memset(omap[p], 0, pk->own_cells[p] * sizeof(int32_t));
+      }
+      pk->own_base = 1;
+    }
+    const int32_t base = pk->own_base;
     for (int i = 0; i < na; ++i) {
       const vp9hip_intra_task *t = &ia[i];
       const int p = t->plane, W = paw[p] >> 2, H = pah[p] >> 2;
       const int cx = t->x >> 2, cy = t->y >> 2, n = 1 << t->tx_size;
-      int32_t *m = lmap[p], *o = omap[p];
-      int l = 0;
+      int32_t *o = omap[p];
+      int l = 0, last = -1;
       parent[i] = i;
 #define DEP(yy, xx)                                  \
   do {                                               \
-    const size_t c_ = (size_t)(yy) * W + (xx);       \
-    if (m[c_] > l) l = m[c_];                        \
-    if (o[c_] >= 0) {                                \
-      const int ra_ = uf_find(parent, o[c_]), rb_ = uf_find(parent, i); \
+    const int32_t v_ = o[(size_t)(yy) * W + (xx)];   \
+    if (v_ >= base && v_ - base != last) {           \
+      last = v_ - base;                              \
+      if (lv[last] > l) l = lv[last];                \
+      const int ra_ = uf_find(parent, last), rb_ = uf_find(parent, i); \
       if (ra_ != rb_) parent[rb_] = ra_;             \
     }                                                \
   } while (0)
@@ -661,15 +1027,15 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
       ++l;
       lv[i] = l;
       if (l > max_level) max_level = l;
-      for (int y = cy; y < cy + n && y < H; ++y)
-        for (int x = cx; x < cx + n && x < W; ++x) {
-          m[(size_t)y * W + x] = l;
-          o[(size_t)y * W + x] = i;
-        }
+      const int ye = cy + n < H ? cy + n : H, xe = cx + n < W ? cx + n : W;
+      for (int y = cy; y < ye; ++y)
+        for (int x = cx; x < xe; ++x) o[(size_t)y * W + x] = base + i;
     }
+    pk->own_base = base + na + 1;
   }
   out->n_intra_waves = max_level;
 
+  PK_MARK("intra levels + union-find");
   /* dense component ids in order of first appearance, sizes */
   int n_comp = 0;
   int32_t *csize = (int32_t *)pk->comp_size.p;
@@ -830,22 +1196,11 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
     out->n_intra_island_tasks = n_isl;
   }
 
+  PK_MARK("islands");
   /* ---- loop-filter masks ---------------------------------------------------------------------- */
   out->sb_rows = sb_rows;
   out->sb_cols = sb_cols;
-  if (P->build_lf_masks) {
-    const size_t n_sb = (size_t)sb_rows * sb_cols;
-    if (vec_reserve(&pk->lf_raw, n_sb * sizeof(lfm_raw)) || vec_reserve(&pk->lfm, n_sb * sizeof(vp9hip_lfm)))
-      PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
-    lfm_raw *raw = (lfm_raw *)pk->lf_raw.p;
-    vp9hip_lfm *lfm = (vp9hip_lfm *)pk->lfm.p;
-    memset(raw, 0, n_sb * sizeof(lfm_raw));
-    for (int i = 0; i < n_blocks; ++i)
-      lf_build_mask(&raw[(size_t)(blocks[i].mi_row >> 3) * sb_cols + (blocks[i].mi_col >> 3)], &blocks[i], lf_skip[i]);
-    for (int r = 0; r < sb_rows; ++r)
-      for (int c = 0; c < sb_cols; ++c)
-        lf_adjust_mask(&raw[(size_t)r * sb_cols + c], &lfm[(size_t)r * sb_cols + c], r * 8, c * 8, mi_rows, mi_cols);
-    out->lfm = lfm;
-  }
+  if (P->build_lf_masks) out->lfm = (const vp9hip_lfm *)pk->lfm.p; /* built in pass 1 */
+  PK_MARK("loop-filter masks");
   return VP9HIP_OK;
 }
