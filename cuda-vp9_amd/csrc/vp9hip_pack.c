@@ -375,11 +375,26 @@ static void counting_sort(const void *src, void *dst, size_t rec, const int32_t 
     memcpy((char *)dst + (size_t)count[key[i]]++ * rec, (const char *)src + (size_t)i * rec, rec);
 }
 
-/* deepest islands first: an island is one workgroup walking its waves one after the other, so the
- * deepest one is the critical path of the launch — and of the loop-filter rows waiting for it */
-static int island_deeper_first(const void *a, const void *b) {
+/* Order of the islands = order in which the island kernel's workgroups are dispatched (a frame has more
+ * islands than the GPU holds workgroups).  The loop filter running beside the walk reaches superblock
+ * (r, c) after about (r + c) superblock steps and needs every island around it finished by then, and an
+ * island takes its depth in waves: earliest deadline first, deadline = (first row + first column) steps
+ * minus the island's own duration (a step of the filter is about 2.2 wave times of the walk; measured,
+ * DESIGN.md §3.3).  Deepest-first, the previous order, made the filter's first superblocks wait for the
+ * shallow islands next to them, which were dispatched last. */
+static int g_isl_w[3] = { 56, 60, 0 };
+static int island_key(const vp9hip_intra_island *x) {
+  int r = (int)(x->reserved & 255), c = (int)((x->reserved >> 16) & 255);
+  if (g_isl_w[2]) {
+    r = r > 0 ? r - 1 : 0;
+    c = c > 0 ? c - 1 : 0;
+  }
+  return g_isl_w[0] * (r + c) - g_isl_w[1] * (int)x->n_waves;
+}
+static int island_deadline_first(const void *a, const void *b) {
   const vp9hip_intra_island *x = (const vp9hip_intra_island *)a, *y = (const vp9hip_intra_island *)b;
-  if (x->n_waves != y->n_waves) return x->n_waves > y->n_waves ? -1 : 1;
+  const int kx = island_key(x), ky = island_key(y);
+  if (kx != ky) return kx < ky ? -1 : 1;
   return x->task_start < y->task_start ? -1 : (x->task_start > y->task_start);
 }
 
@@ -1181,7 +1196,11 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
         }
         a = e;
       }
-      qsort(is, (size_t)n_is, sizeof(*is), island_deeper_first);
+      {
+        const char *e = getenv("VP9HIP_ISLAND_W");
+        if (e) sscanf(e, "%d,%d,%d", &g_isl_w[0], &g_isl_w[1], &g_isl_w[2]);
+      }
+      qsort(is, (size_t)n_is, sizeof(*is), island_deadline_first);
       out->islands = is;
       out->n_islands = n_is;
       out->island_wave_off = wo;

@@ -19,8 +19,17 @@
 extern "C" {
 #endif
 
+#include <stddef.h>
+
 struct VP9Decoder;
+struct VP9Common;
 struct frame_buffer; /* frameBuf, vpx-master/buffers_struct.h:9-15 */
+
+/* Memory for what initBuf() (vp9_decodeframe.c:2242-2270) mallocs and frees for every frame: which = 0..2
+ * the coefficient array of that plane (frameBuf.dqcoeff[plane]), 3 the eob plane (frameBuf.eob).  Page-
+ * locked, owned by the shim, kept (and grown) from frame to frame; valid until the next call with the
+ * same `which` for the same decoder.  The caller must not free it.  NULL on failure. */
+void *vp9hip_shim_frame_memory(struct VP9Common *cm, int which, size_t bytes);
 
 /* Coefficient mode: call once per frame right after initBuf() (vp9_decodeframe.c:2316), before the
  * entropy loop advances frameBuffer->dqcoeff[].  From then on the wrappers run the inverse
@@ -38,6 +47,11 @@ void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_
  * frame-buffer index, so later frames that reference it need no upload.  Repeating the call with the
  * same value is free (a caller may issue it for every frame). */
 void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable);
+
+/* Measurement aid (VP9HIP_SHIM_TRACE=1; a no-op otherwise): marks 0..4 placed in decode_tiles — entry, before
+ * the entropy loop, after it, after the two entry points, before return — split a frame's host time into
+ * set-up / entropy decode / reconstruction entry points / tear-down in the trace printed at exit. */
+void vp9hip_shim_mark(struct VP9Decoder *pbi, int mark);
 
 /* Frees the GPU state kept for a decoder instance (call from vp9_decoder_remove). */
 void vp9hip_shim_release(struct VP9Decoder *pbi);

@@ -22,6 +22,12 @@ Edits (decode_tiles = vp9_decodeframe.c:2303-2639):
       become `if (0)`: the frame wrap_cuda_intra_prediction delivers is already filtered
   E4  initBuf (:2244-2246): no malloc + memset of the frame-sized int64 residual plane
   E5  `X_Fuel(pbi);` (:3567) only for high-bitdepth buffers (it reinterprets the buffer as uint16)
+  E7  initBuf / freeBuf (:2244-2297): the frame-sized eob plane and the three coefficient arrays are
+      taken from vp9hip_shim_frame_memory() — page-locked, kept from frame to frame — instead of
+      malloc + free per frame (~70 MB of fresh pages per 1440p frame, and pageable memory makes every
+      host-to-device copy a staged, synchronous one)
+  E9  vp9hip_shim_mark(pbi, k) at five points of decode_tiles: where the host time of a frame goes, printed
+      with VP9HIP_SHIM_TRACE=1 (no effect otherwise)
   E6  `int n = cm->width * cm->height;` (:2314) sizes dqcoeff[plane] (initBuf :2266) and the block
       lists; coefficient slots cover whole transform blocks, so a frame whose size is not a multiple
       of 8 (or whose last 32x32 transform block overhangs the frame) overruns it (heap corruption,
@@ -49,10 +55,6 @@ def main():
     if gpu_lf:
         hook += "  vp9hip_shim_set_gpu_loop_filter(pbi, 1);\n"
     t = replace_once(t, "  initBuf(frameBuffer, n, cm);\n", hook, "E1 initBuf call")
-    t = replace_once(t, "static const uint8_t *decode_tiles(VP9Decoder *pbi, const uint8_t *data, const uint8_t *data_end) {",
-                     '#include "vp9hip_libvpx_shim.h"\n'
-                     "static const uint8_t *decode_tiles(VP9Decoder *pbi, const uint8_t *data, const uint8_t *data_end) {",
-                     "E1 decode_tiles head")
 
     # E2
     a = t.find("  //frame idct\n")
@@ -84,6 +86,30 @@ def main():
     # E6
     t = replace_once(t, "  int n = cm->width * cm->height;\n",
                      "  int n = 64 * mi_cols_aligned_to_sb(cm->mi_cols) * mi_cols_aligned_to_sb(cm->mi_rows);\n", "E6 n")
+
+    # E7
+    t = replace_once(t, "  buffer->eob = (int *)malloc(src->frame_size * sizeof(int));\n",
+                     "  buffer->eob = (int *)vp9hip_shim_frame_memory(cm, 3, src->frame_size * sizeof(int));\n", "E7 eob malloc")
+    t = replace_once(t, "    buffer->dqcoeff[plane] = (tran_low_t *)malloc(n * sizeof(tran_low_t));\n",
+                     "    buffer->dqcoeff[plane] = (tran_low_t *)vp9hip_shim_frame_memory(cm, plane, n * sizeof(tran_low_t));\n",
+                     "E7 dqcoeff malloc")
+    t = replace_once(t, "static void freeBuf(frameBuf *buffer) {\n  for (int plane = 0; plane < MAX_MB_PLANE; ++plane) {\n"
+                        "    free(buffer->dqcoeff[plane]);\n  }\n\n  free(buffer->residuals);\n  free(buffer->eob);\n",
+                     "static void freeBuf(frameBuf *buffer) {\n  /* eob plane + coefficient arrays belong to the shim */\n"
+                     "  free(buffer->residuals);\n", "E7 freeBuf")
+    t = replace_once(t, "static void initBuf(frameBuf *buffer, int n, VP9_COMMON *cm) {",
+                     "#include \"vp9hip_libvpx_shim.h\"\nstatic void initBuf(frameBuf *buffer, int n, VP9_COMMON *cm) {", "E7 include")
+
+    # E9 (measurement only): phase marks of decode_tiles for VP9HIP_SHIM_TRACE
+    t = replace_once(t, "  frameBuf *frameBuffer = (frameBuf *)malloc(sizeof(frameBuf));\n",
+                     "  vp9hip_shim_mark(pbi, 0);\n  frameBuf *frameBuffer = (frameBuf *)malloc(sizeof(frameBuf));\n", "E9 mark 0")
+    t = replace_once(t, "  //entropy decoder\n", "  vp9hip_shim_mark(pbi, 1);\n  //entropy decoder\n", "E9 mark 1")
+    i = t.find("  //go to start\n")
+    if i < 0:
+        sys.exit("patch_decodeframe: anchor not found: E9 mark 2")
+    t = t[:i] + "  vp9hip_shim_mark(pbi, 2);\n" + t[i:]
+    t = replace_once(t, "  // Get last tile data.\n", "  vp9hip_shim_mark(pbi, 3);\n  // Get last tile data.\n", "E9 mark 3")
+    t = replace_once(t, "  ++fr;\n", "  vp9hip_shim_mark(pbi, 4);\n  ++fr;\n", "E9 mark 4")
 
     # E5
     t = replace_once(t, "    X_Fuel(pbi);\n",

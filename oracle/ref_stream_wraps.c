@@ -116,6 +116,32 @@ void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_
     for (int p = 0; p < 3; ++p) s->dq_start[p] = frameBuffer->dqcoeff[p];
 }
 
+/* the shim's hook of the same name (include/vp9hip_libvpx_shim.h): here plain memory kept per decoder */
+void *vp9hip_shim_frame_memory(struct VP9Common *cm, int which, size_t bytes) {
+  static struct {
+    VP9_COMMON *cm;
+    void *p[4];
+    size_t cap[4];
+  } mem[ORACLE_MAX_DECODERS];
+  if (which < 0 || which > 3) return NULL;
+  for (int i = 0; i < ORACLE_MAX_DECODERS; ++i) {
+    if (mem[i].cm != cm && mem[i].cm != NULL) continue;
+    mem[i].cm = cm;
+    if (bytes > mem[i].cap[which]) {
+      free(mem[i].p[which]);
+      mem[i].p[which] = malloc(bytes + bytes / 8);
+      mem[i].cap[which] = mem[i].p[which] ? bytes + bytes / 8 : 0;
+    }
+    return mem[i].p[which];
+  }
+  return NULL;
+}
+
+void vp9hip_shim_mark(struct VP9Decoder *pbi, int mark) {
+  (void)pbi;
+  (void)mark;
+}
+
 void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable) { state_of(pbi)->filter_here = enable != 0; }
 
 void vp9hip_shim_release(struct VP9Decoder *pbi) {

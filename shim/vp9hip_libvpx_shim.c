@@ -31,6 +31,7 @@
  * there is no CPU fallback.  Out-parameters *gpu_copy / *gpu_run are seconds, as in the
  * reference (vpx-master/inter_cuda_kernel.cu:1069-1101).
  */
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -62,6 +63,9 @@ typedef struct {
   MODE_INFO **open_mi;
   /* GPU loop filter + resident references: pool slot i shadows cm->buffer_pool->
    * frame_bufs[i]; a slot is valid while it holds exactly what the host buffer holds */
+  /* page-locked memory lent to the caller's initBuf (vp9hip_shim_frame_memory): 0..2 coefficient arrays, 3 eob plane */
+  void *frame_mem[4];
+  size_t frame_mem_cap[4];
   int gpu_lf;
   struct {
     const uint8_t *alloc;
@@ -71,6 +75,8 @@ typedef struct {
 
 static shim_state g_state[SHIM_MAX_DECODERS];
 
+static double now_s(void);
+
 /* VP9HIP_SHIM_TRACE=1: where the time of the two entry points goes, summed over the stream and printed
  * at exit (seconds of host wall time; "kernels" are waits for the GPU) */
 static struct {
@@ -79,8 +85,28 @@ static struct {
   double gpu_inter_ms, gpu_intra_ms;
 } g_trace;
 
+static double g_mark_t[5], g_mark_sum[5], g_mark_outside;
+
+void vp9hip_shim_mark(struct VP9Decoder *pbi, int mark) {
+  (void)pbi;
+  if (!g_trace.on || mark < 0 || mark > 4) return;
+  const double t = now_s();
+  if (mark == 0) {
+    if (g_mark_t[4] > 0.0) g_mark_outside += t - g_mark_t[4];
+  } else {
+    g_mark_sum[mark] += t - g_mark_t[mark - 1];
+  }
+  g_mark_t[mark] = t;
+}
+
 static void trace_report(void) {
   if (!g_trace.frames) return;
+  if (g_mark_sum[4] > 0.0)
+    fprintf(stderr,
+            "vp9hip shim: decode_tiles per frame: set-up %.3f ms, entropy decode %.3f ms, reconstruction entry points %.3f ms, "
+            "tear-down %.3f ms; outside decode_tiles (headers, probability adaptation, vpxdec) %.3f ms\n",
+            g_mark_sum[1] * 1e3 / g_trace.frames, g_mark_sum[2] * 1e3 / g_trace.frames, g_mark_sum[3] * 1e3 / g_trace.frames,
+            g_mark_sum[4] * 1e3 / g_trace.frames, g_mark_outside * 1e3 / g_trace.frames);
   const double n = g_trace.frames, ms = 1e3 / n;
   fprintf(stderr,
           "vp9hip shim: %d frames; per frame: gather blocks %.3f ms, pack + list/coefficient upload %.3f ms, reference "
@@ -132,6 +158,25 @@ void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_
     for (int p = 0; p < 3; ++p) s->dq_start[p] = frameBuffer->dqcoeff[p];
 }
 
+void *vp9hip_shim_frame_memory(struct VP9Common *cm, int which, size_t bytes) {
+  /* the decoder's VP9_COMMON is a member of its VP9Decoder (libvpx/vp9/decoder/vp9_decoder.h) */
+  VP9Decoder *pbi = (VP9Decoder *)((char *)cm - offsetof(VP9Decoder, common));
+  shim_state *s = state_of(pbi, cm);
+  if (!s || which < 0 || which > 3) return NULL;
+  if (bytes > s->frame_mem_cap[which]) {
+    /* nothing of an earlier frame is in flight here: the intra wrapper synchronised before it returned */
+    vp9hip_decoder_host_free(s->dec, s->frame_mem[which]);
+    s->frame_mem_cap[which] = 0;
+    s->frame_mem[which] = vp9hip_decoder_host_alloc(s->dec, bytes + bytes / 8);
+    if (!s->frame_mem[which]) {
+      vpx_internal_error(&cm->error, VPX_CODEC_MEM_ERROR, "vp9hip shim: out of page-locked memory");
+      return NULL;
+    }
+    s->frame_mem_cap[which] = bytes + bytes / 8;
+  }
+  return s->frame_mem[which];
+}
+
 void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable) {
   shim_state *s = state_of(pbi, &pbi->common);
   if (!s || s->gpu_lf == (enable != 0)) return; /* callers may repeat the call for every frame */
@@ -142,6 +187,7 @@ void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable) {
 void vp9hip_shim_release(struct VP9Decoder *pbi) {
   for (int i = 0; i < SHIM_MAX_DECODERS; ++i)
     if (g_state[i].pbi == pbi) {
+      for (int k = 0; k < 4; ++k) vp9hip_decoder_host_free(g_state[i].dec, g_state[i].frame_mem[k]);
       vp9hip_decoder_destroy(g_state[i].dec);
       free(g_state[i].blocks);
       memset(&g_state[i], 0, sizeof(g_state[i]));
@@ -303,7 +349,11 @@ static int begin_frame(shim_state *s, VP9_COMMON *cm, VP9Decoder *pbi, int *size
       vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: needs a CONFIG_VP9_HIGHBITDEPTH build (32-bit tran_low_t)");
       return -1;
     }
-    SHIM_CHECK(s, cm, vp9hip_decoder_begin_frame(s->dec, &P, s->blocks, n, &L, dq));
+    /* coefficient arrays the caller got from vp9hip_shim_frame_memory are page-locked and stay untouched
+     * until the frame has been delivered: they travel asynchronously */
+    const int persistent = s->frame_mem[0] && dq[0] == (const int32_t *)s->frame_mem[0] && dq[1] == (const int32_t *)s->frame_mem[1] &&
+                           dq[2] == (const int32_t *)s->frame_mem[2];
+    SHIM_CHECK(s, cm, vp9hip_decoder_begin_frame_ex(s->dec, &P, s->blocks, n, &L, dq, persistent ? VP9HIP_BEGIN_HOST_PERSISTENT : 0));
   } else {
     const int64_t *res[3];
     int32_t rs[3];
@@ -361,8 +411,13 @@ int wrap_cuda_inter_prediction(int n, double *gpu_copy, double *gpu_run, int *si
                                               (int)cm->bit_depth, (cur->flags & YV12_FLAG_HIGHBITDEPTH) != 0, 1));
   const double t1 = now_s();
   SHIM_CHECK(s, cm, vp9hip_decoder_run(s->dec, VP9HIP_PHASE_INTER, ref_slot, slot_of_cur(s, cm), NULL, NULL));
-  SHIM_CHECK(s, cm, vp9hip_decoder_sync(s->dec));
-  SHIM_CHECK(s, cm, vp9hip_decoder_last_run_ms(s->dec, &ms));
+  /* the kernels only read device memory and page-locked arrays nobody touches before the intra wrapper has
+   * delivered the frame: no need to wait here (the reference's out-parameter *gpu_run then reads 0 for
+   * this entry point; VP9HIP_SHIM_TRACE measures it) */
+  if (g_trace.on) {
+    SHIM_CHECK(s, cm, vp9hip_decoder_sync(s->dec));
+    SHIM_CHECK(s, cm, vp9hip_decoder_last_run_ms(s->dec, &ms));
+  }
   g_trace.pack_upload += t_begin - t0;
   g_trace.refs += t1 - t_begin;
   g_trace.inter_wait += now_s() - t1;
