@@ -19,6 +19,7 @@ static const uint8_t kH4[13] = { 1, 2, 1, 2, 4, 2, 4, 8, 4, 8, 16, 8, 16 };
 static const uint8_t kModeToTxType[10] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3 };
 
 #define MAX_ISLAND_TASKS 4096
+#define ISLAND_GROUP_TASKS 192
 
 typedef struct {
   void *p;
@@ -1066,6 +1067,40 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
       comp[i] = root_to_id[r];
       ++csize[comp[i]];
     }
+  }
+  /* Small components are walked TOGETHER: an island (= one workgroup of the island kernel, eight block
+   * slots wide) is the set of components whose first block lies in the same luma superblock, as long as the
+   * set stays under ISLAND_GROUP_TASKS.  A frame of a real stream has thousands of one- or two-block
+   * components; a workgroup each filled the GPU with mostly idle lanes (island walk of the bench frame:
+   * 5853 workgroups, 190 us of the whole GPU).  Levels are per block, so blocks of different components
+   * simply share waves; the per-superblock completion marks work on islands, whatever they contain. */
+  if (n_comp) {
+    const size_t n_sb_all = (size_t)sb_rows * sb_cols;
+    if (vec_reserve(&pk->lvl_map[0], sizeof(int32_t) * (size_t)(n_comp + 1)) || vec_reserve(&pk->lvl_map[1], sizeof(int32_t) * (n_sb_all + 1)))
+      PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+    int32_t *grp = (int32_t *)pk->lvl_map[0].p, *sb_group = (int32_t *)pk->lvl_map[1].p;
+    for (int c = 0; c < n_comp; ++c) grp[c] = -1;
+    for (size_t s = 0; s < n_sb_all; ++s) sb_group[s] = -1;
+    for (int i = 0; i < na; ++i) {
+      const int c = comp[i];
+      if (grp[c] >= 0) continue;
+      grp[c] = c;
+      if (csize[c] > ISLAND_GROUP_TASKS) continue; /* large enough to fill a workgroup on its own */
+      const vp9hip_intra_task *t0 = &ia[i];
+      const int sc = t0->plane ? ss : 0;
+      int q = (t0->y << sc) >> 6, c2 = (t0->x << sc) >> 6;
+      if (q > sb_rows - 1) q = sb_rows - 1;
+      if (c2 > sb_cols - 1) c2 = sb_cols - 1;
+      const int sb = q * sb_cols + c2, g = sb_group[sb];
+      if (g >= 0 && csize[g] + csize[c] <= ISLAND_GROUP_TASKS) {
+        grp[c] = g;
+        csize[g] += csize[c];
+        csize[c] = 0;
+      } else {
+        sb_group[sb] = c;
+      }
+    }
+    for (int i = 0; i < na; ++i) comp[i] = grp[comp[i]];
   }
   /* split: islands (components that fit one workgroup's walk) / big components (global waves) */
   {
