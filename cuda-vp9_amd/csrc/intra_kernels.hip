@@ -99,6 +99,37 @@ __device__ __forceinline__ void predict_column(int mode, int c, const int *E, bo
           p[r] = AVG3(E[-1 - i], E[-2 - i], E[-1 - (i + 2 < BS ? i + 2 : BS - 1)]);
       }
       break;
+    // The four "e" / VP8-style 4x4 predictors of the dispatch table (vpx_dsp_rtcd_defs.pl:46, 51, 57, 70;
+    // intrapred.c:250-280, 331-350, 375-393).  VP9 itself never selects them; the twins exist for the table.
+    case 13:  // D45E: as D45 4x4 but the last sample is AVG3(G, H, H)
+      if (BS == 4) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+          const int i = r + c;
+          p[r] = AVG3(A[i], A[i + 1], A[i + 2 > 7 ? 7 : i + 2]);
+        }
+      }
+      break;
+    case 14:  // D63E
+      if (BS == 4) {
+        p[0] = AVG2(A[c], A[c + 1]);
+        p[1] = AVG3(A[c], A[c + 1], A[c + 2]);
+        p[2] = c < 3 ? AVG2(A[c + 1], A[c + 2]) : AVG3(A[4], A[5], A[6]);
+        p[3] = c < 3 ? AVG3(A[c + 1], A[c + 2], A[c + 3]) : AVG3(A[5], A[6], A[7]);
+      }
+      break;
+    case 15:  // HE: rows smoothed along the left edge, L[-1] = above-left, L[4] = L[3]
+      if (BS == 4) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) p[r] = AVG3(r == 0 ? A[-1] : E[-r], E[-1 - r], r == 3 ? E[-4] : E[-2 - r]);
+      }
+      break;
+    case 16:  // VE: columns smoothed along the above row
+      if (BS == 4) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) p[r] = AVG3(A[c - 1], A[c], A[c + 1]);
+      }
+      break;
     case 4:  // D135 (:109-139): constant along d = c - r, AVG3(E[d-1],E[d],E[d+1]) around E[d]
 #pragma unroll
       for (int r = 0; r < BS; ++r) {

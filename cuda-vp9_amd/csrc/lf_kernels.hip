@@ -133,7 +133,10 @@ __device__ __forceinline__ void lf_controls(unsigned *ctl, const vp9hip_lfm &m, 
     uint64_t l16, l8, l4, a16, a8, a4, mint;
     int level, level_left = 0, level_up = 0;
     const int mr = lane / ncol, c = lane - mr * ncol;
-    if (pl == 0) {
+    // N == 64: the luma masks — for the luma plane, and for the chroma planes of a 4:4:4 frame, which libvpx
+    // filters with vp9_filter_block_plane_ss00 and the same LOOP_FILTER_MASK (LF_PATH_444,
+    // libvpx/vp9/common/vp9_loopfilter.c:1433-1434, 1456-1458); N == 32: the uv masks of 4:2:0
+    if (N == 64) {
       l16 = m.left_y[2]; l8 = m.left_y[1]; l4 = m.left_y[0];
       a16 = m.above_y[2]; a8 = m.above_y[1]; a4 = m.above_y[0];
       mint = m.int_4x4_y;
@@ -179,7 +182,7 @@ __device__ __forceinline__ void lf_controls(unsigned *ctl, const vp9hip_lfm &m, 
         kind = 4;
       }
       int skip_int = -1;  // skip_border_4x4_r (vp9_loopfilter.c:1385-1387)
-      if (pl)
+      if (N == 32)
         for (int r = 0; r < rows_mi; r += 2)
           if (mi_row + r == mi_rows - 1) skip_int = r >> 1;
       // the 16-wide branch of filter_selectively_horiz never filters the interior edge (:465-538)
@@ -313,7 +316,7 @@ __device__ __forceinline__ void lf_sb_body(Pix *tile, unsigned *ctl, const vp9hi
   const int pw = f.awidth[pl], ph = f.aheight[pl];
   const int mi_row = sr * 8;
   const int rows_mi = min(8, mi_rows - mi_row);
-  const int mrows = pl ? ((rows_mi + 1) >> 1) : rows_mi;  // mask rows of this plane
+  const int mrows = N == 32 ? ((rows_mi + 1) >> 1) : rows_mi;  // mask rows of this plane
   // ---- stage the tile: rows y0-8 .. y0+n-1, cols x0-8 .. x0+n-1 (clipped), dword accesses,
   // all loads issued before the first LDS store
   constexpr int tw = n + 8;      // samples per tile row
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(64) void lf_diag_kernel(const vp9hip_lfm *__restric
   const int sr = r_min + blockIdx.x, sc = t - 2 * sr;
   const int pl = blockIdx.y;
   const vp9hip_lfm &m = lfms[sr * sb_cols + sc];
-  if (pl == 0)
+  if (pl == 0 || f.awidth[pl] == f.awidth[0])
     lf_sb_body<Pix, 64>(tile, ctl, m, sr, sc, pl, th, f, mi_rows);
   else
     lf_sb_body<Pix, 32>(tile, ctl, m, sr, sc, pl, th, f, mi_rows);
@@ -414,7 +417,7 @@ __device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9h
   const int y0 = sr * n;
   const int mi_row = sr * 8;
   const int rows_mi = min(8, mi_rows - mi_row);
-  const int mrows = pl ? ((rows_mi + 1) >> 1) : rows_mi;
+  const int mrows = N == 32 ? ((rows_mi + 1) >> 1) : rows_mi;
   unsigned *tile32 = (unsigned *)tile;
 
   bool dead = false;  // a wait timed out: stop waiting (the error flag is set), just finish
@@ -544,7 +547,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   const int y0 = sr * n;
   const int mi_row = sr * 8;
   const int rows_mi = min(8, mi_rows - mi_row);
-  const int mrows = pl ? ((rows_mi + 1) >> 1) : rows_mi;
+  const int mrows = N == 32 ? ((rows_mi + 1) >> 1) : rows_mi;
   const int ncols = min(sb_cols, (pw + n - 1) / n);  // superblocks of this plane row
   bool dead = false;
 
@@ -728,7 +731,13 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         handoff((const unsigned *)(tiles + ((sc - 1) & 1) * TILE), x0 - n, 8, n);
         if (lane == 0) __hip_atomic_store(hprog_mine, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      while (flags[0] < (unsigned)(sc + 1)) __builtin_amdgcn_s_sleep(1);
+      for (int spins = 0; flags[0] < (unsigned)(sc + 1); ++spins) {  // wave 0 of this workgroup: bounded all the same
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > LF_SPIN_LIMIT) {
+          if (lane == 0) atomicExch(err, 1);
+          break;
+        }
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       if (sc > 0) handoff(t32, x0, 0, 8);
       if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restr
   int *hprev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
   int *hmine = progress + pl * sb_rows + sr;
   int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
-  if (pl == 0)
+  if (pl == 0 || f.awidth[pl] == f.awidth[0])
     lf_row2_body<Pix, 64, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
                           gate_done, gate_expected, sb_rows);
   else
@@ -791,7 +800,7 @@ __global__ __launch_bounds__(64) void lf_rows_kernel(const vp9hip_lfm *__restric
   const int sr = blockIdx.x, pl = blockIdx.y;
   int *prev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
   int *mine = progress + pl * sb_rows + sr;
-  if (pl == 0)
+  if (pl == 0 || f.awidth[pl] == f.awidth[0])
     lf_row_body<Pix, 64>(tile, ctl, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
   else
     lf_row_body<Pix, 32>(tile, ctl, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
@@ -807,8 +816,10 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
   if (sb_rows != (frame->aheight[0] + 63) / 64 || sb_cols != (frame->awidth[0] + 63) / 64)
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_loop_filter_frame: %dx%d superblocks do not cover a %dx%d frame",
                 sb_cols, sb_rows, frame->awidth[0], frame->aheight[0]);
-  if (planes == 3 && (frame->awidth[1] * 2 != frame->awidth[0] || frame->aheight[1] * 2 != frame->aheight[0]))
-    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_loop_filter_frame: only 4:2:0 chroma is supported");
+  const bool c420 = frame->awidth[1] * 2 == frame->awidth[0] && frame->aheight[1] * 2 == frame->aheight[0];
+  const bool c444 = frame->awidth[1] == frame->awidth[0] && frame->aheight[1] == frame->aheight[0];
+  if (planes == 3 && !c420 && !c444)
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_loop_filter_frame: chroma must be 4:2:0 or 4:4:4 (libvpx's LF_PATH_SLOW is not implemented)");
   LfThreshDev th;
   memcpy(&th, h_thresh, sizeof(th));
   const FrameDev f = to_dev(frame);
@@ -824,16 +835,27 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
     const size_t need = (size_t)(6 * sb_rows + 1) * sizeof(int);
     int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
     if (rc) return rc;
-    int *progress = (int *)ctx->scratch, *err = progress + 6 * sb_rows;
+    int *progress = (int *)ctx->scratch;
     if (!counters_zeroed) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, st));
-    ctx->lf_err_flag = err;
+    // the time-out flag lives OUTSIDE the counters that are zero-filled for every frame: it stays set until
+    // vp9hip_sync has reported it, however many frames are enqueued behind the one that gave up
+    if (!ctx->lf_err_flag) {
+      VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_err_flag, sizeof(int)));
+      VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(int)));
+    }
+    int *err = ctx->lf_err_flag;
+    ctx->lf_err_armed = true;
     if (mode == 2) {
 // Unused dynamic LDS on top of the kernel's own, so that at most ONE of these workgroups fits a CU (160 KB):
 // a row that waits for islands (vp9hip_intra_islands_lf) must leave the CU's registers to an island
 // workgroup beside it, however many streams are in flight — two filter workgroups on a CU would not.
+// Only the gated launch needs it.  Forward progress of the rows themselves: a row waits for the row above,
+// i.e. for a workgroup with a LOWER blockIdx.x in the same plane; workgroups are dispatched in blockIdx order
+// (x fastest), so the one waited for is always resident or finished — also when sb_rows x planes exceeds the
+// number of CUs (tests/test_gpu_lf.py runs a frame with more rows than that).
 #define LF_LDS_PAD(PIX) (84 * 1024 - (int)sizeof(PIX) * 2 * 72 * 76 - 4096)
 #define LF_ROWS2(PIX, SH)                                                                                       \
-  hipLaunchKernelGGL((lf_rows2_kernel<PIX, SH>), dim3(sb_rows, planes), dim3(256), LF_LDS_PAD(PIX), st, d_lfm, sb_cols, sb_rows, \
+  hipLaunchKernelGGL((lf_rows2_kernel<PIX, SH>), dim3(sb_rows, planes), dim3(256), d_gate ? LF_LDS_PAD(PIX) : 0, st, d_lfm, sb_cols, sb_rows, \
                      th, f, mi_rows, progress, err, d_gate, d_sb_expected)
       if (!frame->hbd)
         LF_ROWS2(uint8_t, 0);

@@ -207,7 +207,7 @@ done:
 }
 
 // ---- intra predictors ------------------------------------------------------------------------
-// mode ids: 0..9 PREDICTION_MODE, 10 DC_128, 11 DC_LEFT, 12 DC_TOP
+// mode ids: 0..9 PREDICTION_MODE, 10 DC_128, 11 DC_LEFT, 12 DC_TOP, 13 D45E, 14 D63E, 15 HE, 16 VE (4x4 only)
 void twin_intra(int mode, int bs, void *dst, ptrdiff_t stride, const void *above, const void *left, int bd, int hbd) {
   vp9hip_ctx *c = ctx();
   if (!c) return;
@@ -238,7 +238,7 @@ void twin_intra(int mode, int bs, void *dst, ptrdiff_t stride, const void *above
   if (mode == 10) have_top = have_left = 0;
   if (mode == 11) have_top = 0;
   if (mode == 12) have_left = 0;
-  t.mode = (uint8_t)(mode >= 10 ? 0 : mode);
+  t.mode = (uint8_t)(mode >= 10 && mode <= 12 ? 0 : mode);
   t.flags = (uint8_t)(have_top | (have_left << 1) | 4 | 8);
   int32_t wave_start[2] = { 0, 1 };
   vp9hip_frame f = one_plane(d_p, fw, fh, fs, bd, hbd);
@@ -456,6 +456,13 @@ INTRA_TWIN(vpx_tm_predictor_4x4_hip, vpx_highbd_tm_predictor_4x4_hip, 9, 4)
 INTRA_TWIN(vpx_tm_predictor_8x8_hip, vpx_highbd_tm_predictor_8x8_hip, 9, 8)
 INTRA_TWIN(vpx_tm_predictor_16x16_hip, vpx_highbd_tm_predictor_16x16_hip, 9, 16)
 INTRA_TWIN(vpx_tm_predictor_32x32_hip, vpx_highbd_tm_predictor_32x32_hip, 9, 32)
+// 8-bit only (vpx_dsp_rtcd_defs.pl:46, 51, 57, 70 have no highbd counterparts)
+#define INTRA_TWIN8(lo, mode) \
+  extern "C" void lo(uint8_t *d, ptrdiff_t s, const uint8_t *a, const uint8_t *l) { twin_intra(mode, 4, d, s, a, l, 8, 0); }
+INTRA_TWIN8(vpx_d45e_predictor_4x4_hip, 13)
+INTRA_TWIN8(vpx_d63e_predictor_4x4_hip, 14)
+INTRA_TWIN8(vpx_he_predictor_4x4_hip, 15)
+INTRA_TWIN8(vpx_ve_predictor_4x4_hip, 16)
 LPF_TWIN3(vpx_lpf_horizontal_4_hip, vpx_highbd_lpf_horizontal_4_hip, 0, 4, 0)
 LPF_TWIN6(vpx_lpf_horizontal_4_dual_hip, vpx_highbd_lpf_horizontal_4_dual_hip, 0, 4)
 LPF_TWIN3(vpx_lpf_horizontal_8_hip, vpx_highbd_lpf_horizontal_8_hip, 0, 8, 0)

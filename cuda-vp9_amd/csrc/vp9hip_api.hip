@@ -42,6 +42,7 @@ extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->lf_err_flag) (void)hipFree(ctx->lf_err_flag);
   if (ctx->resid) (void)hipFree(ctx->resid);
   if (ctx->ev_resid_start) {
     (void)hipEventDestroy(ctx->ev_resid_start);
@@ -74,11 +75,16 @@ extern "C" void *vp9hip_stream(vp9hip_ctx *ctx) { return ctx ? (void *)ctx->stre
 extern "C" int vp9hip_sync(vp9hip_ctx *ctx) {
   if (!ctx) return VP9HIP_EINVAL;
   VP9HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->lf_err_flag) {
+  if (ctx->lf_err_flag && ctx->lf_err_armed) {
     int flag = 0;
     VP9HIP_CHECK(ctx, hipMemcpy(&flag, ctx->lf_err_flag, sizeof(flag), hipMemcpyDeviceToHost));
-    ctx->lf_err_flag = NULL;
-    if (flag) VP9HIP_FAIL(ctx, VP9HIP_EDEVICE, "loop filter: a superblock row timed out waiting for the row above");
+    ctx->lf_err_armed = false;
+    if (flag) {
+      VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(int)));  // reported once
+      VP9HIP_FAIL(ctx, VP9HIP_EDEVICE,
+                  "loop filter: a superblock row gave up waiting (for the row above or for the intra islands around it); "
+                  "the frames enqueued since the last synchronisation are not valid");
+    }
   }
   return VP9HIP_OK;
 }

@@ -443,6 +443,11 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
     DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: destination slot geometry differs from the frame parameters");
   DEC_HIP(dec, hipSetDevice(dec->ctx->device));
   hipStream_t st = dec->ctx->stream;
+  // a run that failed half-way may have left the head-start bookkeeping of its frame behind (the residual
+  // pre-pass and the zero-filled counters are matched to the island launch by pointer): start clean
+  dec->ctx->resid_tasks = nullptr;
+  dec->ctx->resid_coeffs = nullptr;
+  dec->ctx->lf_zeroed_rows = dec->ctx->lf_zeroed_cols = 0;
   DEC_HIP(dec, hipStreamWaitEvent(st, S->uploaded, 0));
   DEC_CTX(dec, vp9hip_timer_begin(dec->ctx, TIMER_RUN));
 
@@ -522,7 +527,7 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
                                            (const vp9hip_intra_island *)S->d_islands.p, P->n_islands,
                                            (const int32_t *)S->d_wave_off.p, coeffs, (const int32_t *)S->d_sb_expected.p,
                                            (const vp9hip_lfm *)S->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
-                                           S->params.ss_x ? 3 : 1));
+                                           3));
       phases &= ~VP9HIP_PHASE_LF;
     } else {
       if (P->n_islands)
@@ -545,7 +550,7 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
       DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: no loop-filter masks (set params.build_lf_masks or pass them)");
     }
     DEC_CTX(dec, vp9hip_loop_filter_frame(dec->ctx, (const vp9hip_lfm *)S->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
-                                          S->params.ss_x ? 3 : 1));
+                                          3));
   }
   DEC_CTX(dec, vp9hip_timer_end(dec->ctx, TIMER_RUN));
   DEC_HIP(dec, hipEventRecord(S->done, st));

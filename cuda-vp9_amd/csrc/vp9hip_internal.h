@@ -17,7 +17,8 @@ struct vp9hip_ctx {
   void *scratch;
   size_t scratch_bytes;
   int cu_count;
-  int *lf_err_flag;  // device flag: loop-filter wavefront spin timed out (checked by vp9hip_sync)
+  int *lf_err_flag;  // device flag (own allocation): a loop-filter wait timed out; set until vp9hip_sync reports it
+  bool lf_err_armed; // a loop filter was launched since the flag was last read
   void *d_taps;  // packed i8 convolve taps (inter fast path)
   hipEvent_t *ev_begin, *ev_end;  // VP9HIP_TIMER_SLOTS each, created lazily
   // overlap of the intra island walk with the loop filter (vp9hip_intra_islands_lf)

@@ -194,6 +194,11 @@ void vpx_d63_predictor_16x16_hip(uint8_t *dst, ptrdiff_t stride, const uint8_t *
 void vpx_highbd_d63_predictor_16x16_hip(uint16_t *dst, ptrdiff_t stride, const uint16_t *above, const uint16_t *left, int bd);
 void vpx_d63_predictor_32x32_hip(uint8_t *dst, ptrdiff_t stride, const uint8_t *above, const uint8_t *left);
 void vpx_highbd_d63_predictor_32x32_hip(uint16_t *dst, ptrdiff_t stride, const uint16_t *above, const uint16_t *left, int bd);
+/* 8-bit only, 4x4 only (libvpx/vpx_dsp/vpx_dsp_rtcd_defs.pl:46, 51, 57, 70; VP9 never selects them) */
+void vpx_d45e_predictor_4x4_hip(uint8_t *dst, ptrdiff_t stride, const uint8_t *above, const uint8_t *left);
+void vpx_d63e_predictor_4x4_hip(uint8_t *dst, ptrdiff_t stride, const uint8_t *above, const uint8_t *left);
+void vpx_he_predictor_4x4_hip(uint8_t *dst, ptrdiff_t stride, const uint8_t *above, const uint8_t *left);
+void vpx_ve_predictor_4x4_hip(uint8_t *dst, ptrdiff_t stride, const uint8_t *above, const uint8_t *left);
 void vpx_tm_predictor_4x4_hip(uint8_t *dst, ptrdiff_t stride, const uint8_t *above, const uint8_t *left);
 void vpx_highbd_tm_predictor_4x4_hip(uint16_t *dst, ptrdiff_t stride, const uint16_t *above, const uint16_t *left, int bd);
 void vpx_tm_predictor_8x8_hip(uint8_t *dst, ptrdiff_t stride, const uint8_t *above, const uint8_t *left);

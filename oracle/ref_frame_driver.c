@@ -241,8 +241,16 @@ int ref_intra_frame(const int32_t *blocks, int n_blocks, int w, int h, int ss, i
 
 /* Loop-filter masks + filtering through the reference's driver, any BLOCK_SIZE.
  * lvl table: every block carries its own level; blocks with equal level share a segment id. */
+int ref_lf_frame3(const int32_t *blocks, int n_blocks, int aw, int ah, void *const planes[3], const int strides[3],
+                  int bd, int hbd, int sharpness, void *lfm_out, int do_filter, int chroma_ss);
 int ref_lf_frame2(const int32_t *blocks, int n_blocks, int aw, int ah, void *const planes[3], const int strides[3],
                   int bd, int hbd, int sharpness, void *lfm_out, int do_filter) {
+  return ref_lf_frame3(blocks, n_blocks, aw, ah, planes, strides, bd, hbd, sharpness, lfm_out, do_filter, 1);
+}
+/* chroma_ss 1: 4:2:0 (LF_PATH_420); 0: 4:4:4 — every plane through vp9_filter_block_plane_ss00 with the same
+ * mask record (LF_PATH_444, libvpx/vp9/common/vp9_loopfilter.c:1433-1458) */
+int ref_lf_frame3(const int32_t *blocks, int n_blocks, int aw, int ah, void *const planes[3], const int strides[3],
+                  int bd, int hbd, int sharpness, void *lfm_out, int do_filter, int chroma_ss) {
   VP9_COMMON *cm = (VP9_COMMON *)calloc(1, sizeof(*cm));
   const int mi_rows = ah / 8, mi_cols = aw / 8;
   const int sb_rows = (mi_rows + 7) / 8, sb_cols = (mi_cols + 7) / 8;
@@ -285,15 +293,20 @@ int ref_lf_frame2(const int32_t *blocks, int n_blocks, int aw, int ah, void *con
       vp9_adjust_mask(cm, mi_row, mi_col, lfm);
       if (!do_filter) continue;
       for (int p = 0; p < 3; ++p) {
-        const int ss = p ? 1 : 0;
+        const int ss = p ? chroma_ss : 0;
         const size_t off = (size_t)((mi_row * 8) >> ss) * strides[p] + ((mi_col * 8) >> ss);
         pl[p].subsampling_x = pl[p].subsampling_y = ss;
         pl[p].dst.stride = strides[p];
         pl[p].dst.buf = hbd ? CONVERT_TO_BYTEPTR((uint16_t *)planes[p] + off) : (uint8_t *)planes[p] + off;
       }
       vp9_filter_block_plane_ss00(cm, &pl[0], mi_row, lfm);
-      vp9_filter_block_plane_ss11(cm, &pl[1], mi_row, lfm);
-      vp9_filter_block_plane_ss11(cm, &pl[2], mi_row, lfm);
+      if (chroma_ss) {
+        vp9_filter_block_plane_ss11(cm, &pl[1], mi_row, lfm);
+        vp9_filter_block_plane_ss11(cm, &pl[2], mi_row, lfm);
+      } else {
+        vp9_filter_block_plane_ss00(cm, &pl[1], mi_row, lfm);
+        vp9_filter_block_plane_ss00(cm, &pl[2], mi_row, lfm);
+      }
     }
   }
   memcpy(lfm_out, cm->lf.lfm, (size_t)sb_rows * sb_cols * sizeof(LOOP_FILTER_MASK));
@@ -525,7 +538,7 @@ int ref_recon_frame(const int32_t *blocks, int n_blocks, int w, int h, int ss, i
     if (!b2 || !lfm) return -1;
     memcpy(b2, blocks, sizeof(int32_t) * REC * (size_t)n_blocks);
     for (int i = 0; i < n_blocks; ++i) b2[REC * i + 4] = lf_skip[i];
-    const int rc = ref_lf_frame2(b2, n_blocks, mi_cols * 8, mi_rows * 8, cur_planes, cur_strides, bd, hbd, sharpness, lfm, 1);
+    const int rc = ref_lf_frame3(b2, n_blocks, mi_cols * 8, mi_rows * 8, cur_planes, cur_strides, bd, hbd, sharpness, lfm, 1, ss);
     free(b2);
     free(lfm);
     if (rc < 0) return rc;

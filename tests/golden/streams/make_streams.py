@@ -43,6 +43,8 @@ STREAMS = {
     # 10-bit profile 2, width and height multiples of 64 (the UNCHANGED reference driver reads
     # size_for_mb out of bounds otherwise, vp9_decodeframe.c:2489-2534)
     "s704_10": (704, 576, 6, 710, 6, 2, 10, "420", 0.4, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=2", "--cq-level=30", "--tile-columns=1", "--lag-in-frames=0", "--passes=1"], False),
+    # 4:4:4 (profile 1): chroma planes as large as luma, loop-filtered with the luma masks (LF_PATH_444)
+    "s352_444": (352, 288, 6, 444, 3, 2, 8, "444", 0.4, 0, ["--profile=1", "--cpu-used=2", "--cq-level=30", "--lag-in-frames=0", "--passes=1"], False),
     # BASELINE.json-sized streams (SURVEY §8d / BASELINE.md §2)
     "S-1440": (2560, 1440, 60, 1440, 5, 3, 8, "420", 0.1, 0, ["--cpu-used=2", "--cq-level=24", "--tile-columns=3", "--lag-in-frames=0", "--passes=1"], True),
     "S-2160": (3840, 2160, 30, 2160, 23, -17, 8, "420", 0.0, 8, ["--cpu-used=4", "--cq-level=32", "--tile-columns=4", "--lag-in-frames=0", "--passes=1"], True),

@@ -69,3 +69,33 @@ def test_loop_filter_handoff_is_stable_under_repetition(hip, oracle):
         assert frame_check.frame_md5(got, wl) == want, f"iteration {it}"
     job.free()
     ctx.close()
+
+
+def test_loop_filter_gives_up_cleanly_when_an_island_never_reports(hip, oracle):
+    """The overlapped pair (island walk || loop filter): a filter row waits, bounded, for the islands around its
+    superblock.  A gate that can never open (here: one more island announced for a superblock than exists)
+    must end as an ERROR from vp9hip_sync — never as a hang or a silently wrong frame — stay reported
+    exactly once, and leave the context usable."""
+    import workload
+    import cuda_vp9_amd.pipeline as pipeline
+    wl = workload.make_frame_workload(352, 288, seed=5, intra_frac=0.3)
+    ctx = hip.Context(0)
+    job = pipeline.FrameJob(ctx, wl)
+    job.run()
+    ctx.sync()
+    good = job.download()
+    bad = wl["island_sb_expected"].copy()
+    bad[len(bad) // 2] += 1
+    good_buf, job.d_sb_expected = job.d_sb_expected, ctx.alloc(bad)
+    job.run()
+    with pytest.raises(hip.Vp9HipError, match="gave up waiting"):
+        ctx.sync()
+    ctx.sync()  # reported once
+    job.d_sb_expected.free()
+    job.d_sb_expected = good_buf
+    job.run()
+    ctx.sync()
+    again = job.download()
+    assert all(np.array_equal(a, b) for a, b in zip(good, again))
+    job.free()
+    ctx.close()

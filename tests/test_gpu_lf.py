@@ -30,7 +30,10 @@ def smooth_planes(rng, dims, bd, dt):
 
 
 @pytest.mark.parametrize("W,H,bd,hbd,sharp", [(256, 192, 8, False, 0), (200, 136, 8, False, 3),
-                                                (328, 200, 10, True, 0), (136, 72, 12, True, 6)])
+                                                (328, 200, 10, True, 0), (136, 72, 12, True, 6),
+                                                # 100 superblock rows x 3 planes = 300 workgroups > 256 CUs: rows
+                                                # wait for rows that must already be resident (dispatch order)
+                                                (136, 6400, 8, False, 0)])
 def test_loop_filter_frame_matches_oracle(hip, oracle, W, H, bd, hbd, sharp):
     rng = np.random.default_rng(400 + W + bd)
     dt = np.uint16 if hbd else np.uint8

@@ -40,6 +40,21 @@ def test_intra_twins_match_libvpx_md5(hip, bs):
         assert hashlib.md5(src.tobytes()).hexdigest() == KAT["highbd12"][str(bs)][k], (bs, nm)
 
 
+def test_extra_4x4_twins_match_golden(hip):
+    """vpx_d45e / d63e / he / ve_predictor_4x4 (never selected by VP9, but prototypes of the dispatch table):
+    expected blocks from the reference's object code (tests/golden/make_intra_e.py)."""
+    lib = hip.lib()
+    g = np.load(os.path.join(G, "intra_e.npz"))
+    for nm in ("d45e", "d63e", "he", "ve"):
+        for i in range(len(g["above"])):
+            dst = np.zeros((4, 4), np.uint8)
+            above = np.ascontiguousarray(g["above"][i])
+            left = np.ascontiguousarray(g["left"][i])
+            getattr(lib, f"vpx_{nm}_predictor_4x4_hip")(u8p(dst), ctypes.c_ssize_t(4), ptr_at(above, 0, 16), u8p(left))
+            assert _err(lib) == ""
+            assert np.array_equal(dst, g[nm][i]), (nm, i)
+
+
 def test_txfm_twins_match_golden(hip):
     lib = hip.lib()
     z = np.load(os.path.join(G, "txfm.npz"))

@@ -51,7 +51,7 @@ def check(decoder, directory, name):
     assert not bad, f"{name}: frames {bad[:8]} differ, e.g. {got[bad[0]]} != {want[bad[0]]}"
 
 
-@pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10"])
+@pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444"])
 def test_stream_md5_patched_driver(name):
     check(HIP, SMALL, name)
 
