@@ -65,7 +65,11 @@ gcc -std=gnu99 $CF -include "$OUT/simd_to_c.h" -include "$HERE/ref_decodeframe_p
 TMP="$(mktemp -d)"; trap 'rm -rf "$TMP"' EXIT
 python3 "$HERE/patch_decodeframe.py" "$DF" "$TMP/vp9_decodeframe_patched.c"
 gcc -std=gnu99 $CF -include "$OUT/simd_to_c.h" -include "$HERE/ref_decodeframe_prelude.h" -c "$TMP/vp9_decodeframe_patched.c" -o "$OUT/decodeframe_patched.o"
+python3 "$HERE/patch_decodeframe.py" --decoder-c "$L/vp9/decoder/vp9_decoder.c" "$TMP/vp9_decoder_patched.c"
+gcc -std=gnu99 $CF -include "$OUT/simd_to_c.h" -c "$TMP/vp9_decoder_patched.c" -o "$OUT/decoder_patched.o"
 rm -rf "$TMP"
+# the patched driver variants take the patched vp9_decoder.o: the archive's own copy must not be pulled in first
+PATCHED="$OUT/decodeframe_patched.o $OUT/decoder_patched.o"
 
 # ---- the command-line tools and their third-party C++ (libwebm, libyuv: CONFIG_WEBM_IO / CONFIG_LIBYUV) -
 TCF="-O2 -fPIC -w -ffunction-sections -fdata-sections $INC -I$L/third_party/libwebm -I$L/third_party/libyuv/include"
@@ -91,15 +95,15 @@ ENC_TOOLS="$OUT/tools/vpxenc.o $OUT/tools/args.o $OUT/tools/ivfdec.o $OUT/tools/
 gcc -std=gnu99 $CF -Wall -Wno-unused-function -include "$OUT/simd_to_c.h" -c "$HERE/ref_stream_wraps.c" -o "$OUT/ref_stream_wraps.o"
 LINK="-Wl,--gc-sections -lm -lpthread"
 g++ -o "$OUT/vpxdec_cA" $DEC_TOOLS "$OUT/decodeframe_unchanged.o" "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" $LINK
-g++ -o "$OUT/vpxdec_c" $DEC_TOOLS "$OUT/decodeframe_patched.o" "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" $LINK
-g++ -o "$OUT/vpxenc_c" $ENC_TOOLS "$OUT/decodeframe_patched.o" "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" $LINK
+g++ -o "$OUT/vpxdec_c" $DEC_TOOLS $PATCHED "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" $LINK
+g++ -o "$OUT/vpxenc_c" $ENC_TOOLS $PATCHED "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" $LINK
 
 # ---- the product: the same objects against libvp9hip_shim.so ----------------------------------------
 if [ -f "$ROOT/shim/build/libvp9hip_shim.so" ]; then
   RP="-Wl,-rpath,\$ORIGIN -Wl,-rpath,\$ORIGIN/../../cuda-vp9_amd"
   g++ -o "$ROOT/shim/build/vpxdec_hipA" $DEC_TOOLS "$OUT/decodeframe_unchanged.o" "$OUT/libvpxfull.a" \
       -L"$ROOT/shim/build" -lvp9hip_shim -L"$ROOT/cuda-vp9_amd" -lvp9hip $RP $LINK
-  g++ -o "$ROOT/shim/build/vpxdec_hip" $DEC_TOOLS "$OUT/decodeframe_patched.o" "$OUT/libvpxfull.a" \
+  g++ -o "$ROOT/shim/build/vpxdec_hip" $DEC_TOOLS $PATCHED "$OUT/libvpxfull.a" \
       -L"$ROOT/shim/build" -lvp9hip_shim -L"$ROOT/cuda-vp9_amd" -lvp9hip $RP $LINK
   echo "built shim/build/vpxdec_hipA, vpxdec_hip"
 else

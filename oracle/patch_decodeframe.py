@@ -26,6 +26,8 @@ Edits (decode_tiles = vp9_decodeframe.c:2303-2639):
       taken from vp9hip_shim_frame_memory() — page-locked, kept from frame to frame — instead of
       malloc + free per frame (~70 MB of fresh pages per 1440p frame, and pageable memory makes every
       host-to-device copy a staged, synchronous one)
+  E8  (other file: `patch_decodeframe.py --decoder-c <vp9_decoder.c> <out>`) vp9_decoder_remove calls
+      vp9hip_shim_release(pbi): GPU state does not outlive the decoder (`vpxdec --loops=N`)
   E9  vp9hip_shim_mark(pbi, k) at five points of decode_tiles: where the host time of a frame goes, printed
       with VP9HIP_SHIM_TRACE=1 (no effect otherwise)
   E6  `int n = cm->width * cm->height;` (:2314) sizes dqcoeff[plane] (initBuf :2266) and the block
@@ -45,7 +47,18 @@ def replace_once(text, old, new, what, start=0):
     return text[:i] + new + text[i + len(old):]
 
 
+def patch_decoder_c(src, dst):
+    """E8: vp9_decoder_remove (libvpx/vp9/decoder/vp9_decoder.c:216) releases the shim's per-decoder state."""
+    t = open(src, encoding="utf-8", errors="surrogateescape").read()
+    t = replace_once(t, "void vp9_decoder_remove(VP9Decoder *pbi) {\n  int i;\n\n  if (!pbi) return;\n",
+                     "#include \"vp9hip_libvpx_shim.h\"\nvoid vp9_decoder_remove(VP9Decoder *pbi) {\n  int i;\n\n"
+                     "  if (!pbi) return;\n  vp9hip_shim_release(pbi);\n", "E8 vp9_decoder_remove")
+    open(dst, "w", encoding="utf-8", errors="surrogateescape").write(t)
+
+
 def main():
+    if sys.argv[1] == "--decoder-c":
+        return patch_decoder_c(sys.argv[2], sys.argv[3])
     src, dst = sys.argv[1], sys.argv[2]
     gpu_lf = "--keep-cpu-loop-filter" not in sys.argv[3:]
     t = open(src, encoding="utf-8", errors="surrogateescape").read()

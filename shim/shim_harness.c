@@ -14,6 +14,7 @@
  * Block record: the 35-int32 layout of oracle/ref_frame_driver.c.
  */
 #include <stdio.h>
+#include <setjmp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -247,10 +248,17 @@ int shimtest_frame(void *hp, const int32_t *blocks, int n_blocks, int w, int h, 
     vp9hip_shim_attach_frame_buffer(pbi, coefficient_mode ? &fb : NULL);
     if (opts) vp9hip_shim_set_gpu_loop_filter_once(H, pbi, gpu_lf);
     times[0] = times[1] = times[2] = times[3] = 0.0;
-    if (inter_frame)
-      wrap_cuda_inter_prediction(w * h, &times[0], &times[1], size_for_mb, &MiBuf, cm, pbi, 1, 1 << log2_tile_cols, fb.residuals);
-    if (cm->error.error_code == VPX_CODEC_OK)
+    /* the trap libvpx installs around a frame (vp9_receive_compressed_data, libvpx/vp9/decoder/vp9_decoder.c:
+     * 458-466): an error inside a wrapper unwinds to here with longjmp, past the wrapper's own frames */
+    if (setjmp(cm->error.jmp)) {
+      cm->error.setjmp = 0;
+    } else {
+      cm->error.setjmp = 1;
+      if (inter_frame)
+        wrap_cuda_inter_prediction(w * h, &times[0], &times[1], size_for_mb, &MiBuf, cm, pbi, 1, 1 << log2_tile_cols, fb.residuals);
       wrap_cuda_intra_prediction(&times[2], &times[3], size_for_mb, &MiBuf, cm, pbi, 1, 1 << log2_tile_cols, &fb);
+      cm->error.setjmp = 0;
+    }
     rc = (int)cm->error.error_code;
     if (rc && errbuf) snprintf(errbuf, (size_t)errbuf_len, "%s", cm->error.detail);
     for (int p = 0; p < 3 && !rc; ++p) {

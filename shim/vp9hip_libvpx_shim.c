@@ -31,6 +31,7 @@
  * there is no CPU fallback.  Out-parameters *gpu_copy / *gpu_run are seconds, as in the
  * reference (vpx-master/inter_cuda_kernel.cu:1069-1101).
  */
+#include <pthread.h>
 #include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -66,6 +67,7 @@ typedef struct {
   /* page-locked memory lent to the caller's initBuf (vp9hip_shim_frame_memory): 0..2 coefficient arrays, 3 eob plane */
   void *frame_mem[4];
   size_t frame_mem_cap[4];
+  int creating;
   int gpu_lf;
   struct {
     const uint8_t *alloc;
@@ -73,7 +75,11 @@ typedef struct {
   } resident[VP9HIP_POOL_SLOTS];
 } shim_state;
 
+/* One record per decoder instance (VP9Decoder*), found under a lock: decoder threads of one process — one per
+ * GPU, each with its own VP9Decoder — create, look up and release their records concurrently.  Everything else
+ * in a record is only touched by the thread that owns that decoder (libvpx's contract for a codec instance). */
 static shim_state g_state[SHIM_MAX_DECODERS];
+static pthread_mutex_t g_state_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static double now_s(void);
 
@@ -126,27 +132,39 @@ static double now_s(void) {
 
 static shim_state *state_of(VP9Decoder *pbi, VP9_COMMON *cm) {
   int free_i = -1;
-  for (int i = 0; i < SHIM_MAX_DECODERS; ++i) {
-    if (g_state[i].pbi == pbi) return &g_state[i];
+  shim_state *s = NULL;
+  pthread_mutex_lock(&g_state_lock);
+  for (int i = 0; i < SHIM_MAX_DECODERS && !s; ++i) {
+    if (g_state[i].pbi == pbi) s = &g_state[i];
     if (!g_state[i].pbi && free_i < 0) free_i = i;
   }
-  if (free_i < 0) {
+  if (!s && free_i >= 0) {
+    s = &g_state[free_i];
+    memset(s, 0, sizeof(*s));
+    s->pbi = pbi; /* reserves the slot; the GPU objects follow outside the lock */
+    s->creating = 1;
+  }
+  pthread_mutex_unlock(&g_state_lock);
+  if (!s) {
     vpx_internal_error(&cm->error, VPX_CODEC_MEM_ERROR, "vp9hip shim: too many decoder instances");
     return NULL; /* reached only when no setjmp trap is installed */
   }
-  shim_state *s = &g_state[free_i];
-  memset(s, 0, sizeof(*s));
-  const char *dev = getenv("VP9HIP_DEVICE");
-  if (getenv("VP9HIP_SHIM_TRACE") && !g_trace.on) {
-    g_trace.on = 1;
-    atexit(trace_report);
+  if (s->creating) {
+    const char *dev = getenv("VP9HIP_DEVICE");
+    if (getenv("VP9HIP_SHIM_TRACE") && !g_trace.on) {
+      g_trace.on = 1;
+      atexit(trace_report);
+    }
+    int rc = vp9hip_decoder_create(dev ? atoi(dev) : 0, &s->dec);
+    if (rc != VP9HIP_OK) {
+      pthread_mutex_lock(&g_state_lock);
+      memset(s, 0, sizeof(*s));
+      pthread_mutex_unlock(&g_state_lock);
+      vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: %s", vp9hip_last_error(NULL));
+      return NULL;
+    }
+    s->creating = 0;
   }
-  int rc = vp9hip_decoder_create(dev ? atoi(dev) : 0, &s->dec);
-  if (rc != VP9HIP_OK) {
-    vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: %s", vp9hip_last_error(NULL));
-    return NULL;
-  }
-  s->pbi = pbi;
   return s;
 }
 
@@ -185,13 +203,21 @@ void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable) {
 }
 
 void vp9hip_shim_release(struct VP9Decoder *pbi) {
+  shim_state old;
+  int found = 0;
+  pthread_mutex_lock(&g_state_lock);
   for (int i = 0; i < SHIM_MAX_DECODERS; ++i)
     if (g_state[i].pbi == pbi) {
-      for (int k = 0; k < 4; ++k) vp9hip_decoder_host_free(g_state[i].dec, g_state[i].frame_mem[k]);
-      vp9hip_decoder_destroy(g_state[i].dec);
-      free(g_state[i].blocks);
+      old = g_state[i];
       memset(&g_state[i], 0, sizeof(g_state[i]));
+      found = 1;
+      break;
     }
+  pthread_mutex_unlock(&g_state_lock);
+  if (!found) return;
+  for (int k = 0; k < 4; ++k) vp9hip_decoder_host_free(old.dec, old.frame_mem[k]);
+  vp9hip_decoder_destroy(old.dec);
+  free(old.blocks);
 }
 
 #define SHIM_CHECK(s, cm, expr)                                                                        \

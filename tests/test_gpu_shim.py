@@ -193,6 +193,33 @@ def test_residual_plane_mode_refuses_8bit_frames(harness, hip, oracle):
     assert "high-bitdepth" in err
 
 
+def test_error_unwinds_through_libvpx_trap_and_the_decoder_stays_usable(harness, hip, oracle):
+    """A failing wrapper reports through vpx_internal_error, which longjmps to the trap libvpx installs around a
+    frame (the harness installs the same one): the call stack of the wrapper is abandoned half-way.  Everything
+    the shim owns lives in its per-decoder state, so the SAME decoder instance must decode the next, valid
+    frame correctly — nothing leaked, no half-open frame left behind."""
+    W, H, bd = 192, 128, 8
+    rng = np.random.default_rng(77)
+    dims, crop = _dims(W, H)
+    blocks = blockgen.gen_blocks(rng, W, H, hip.BLOCK_DTYPE)
+    refs = [[np.ascontiguousarray(blockgen_noise(rng, d[1], d[0], bd)).astype(np.uint8) for d in dims] for _ in range(3)]
+    coef, eob = blockgen.gen_coeffs(rng, blocks, W, H, bd)
+    expect, L, allc = _expected(hip, oracle, blocks, W, H, bd, [(W, H)] * 3, refs, coef, eob, 0, 0)
+    recs = blockgen.to_ref_records(blocks)
+    h = harness.shimtest_create()
+    for attempt in range(3):
+        # residual-plane mode on an 8-bit frame: refused inside the inter wrapper, after the state was touched
+        res = [np.zeros((d[1], d[0]), np.int64) for d in dims]
+        got = [np.zeros((d[1], d[0]), np.uint8) for d in dims]
+        rc, err, _ = _call(harness, h, recs, W, H, bd, 0, False, True, False, refs, [(W, H)] * 3, coef, eob, res, got)
+        assert rc != 0 and "high-bitdepth" in err
+        got = [np.zeros((d[1], d[0]), np.uint8) for d in dims]
+        rc, err, _ = _call(harness, h, recs, W, H, bd, 0, False, True, True, refs, [(W, H)] * 3, coef, eob, None, got)
+        assert rc == 0, err
+        _assert_equal(got, expect)
+    harness.shimtest_destroy(ctypes.c_void_p(h))
+
+
 def _lf_oracle(hip, oracle, planes, L, dims, bd, sharp):
     """Loop filter of `planes` in place through the oracle, masks from the C packer (pinned equal to
     vp9_build_mask + vp9_adjust_mask), thresholds from vp9hip_lf_frame_init (pinned equal to libvpx's)."""
