@@ -177,10 +177,13 @@ def stream_leg():
     big = os.path.join(ROOT, "tests", "streams_big")
     ivf, gold = os.path.join(big, "S-1440.ivf"), os.path.join(big, "S-1440.md5")
     hipdec, cdec = os.path.join(ROOT, "shim", "build", "vpxdec_hip"), os.path.join(ROOT, "oracle", "_ref", "vpx", "vpxdec_c")
+    mtdec = os.path.join(ROOT, "shim", "build", "vpxdec_hip_mt")
     if not all(os.path.exists(p) for p in (ivf, gold, hipdec, cdec)):
         return {"skipped": "tests/streams_big/S-1440.ivf or the vpxdec builds are absent (tests/golden/streams/make_streams.py --big, oracle/build_refvpx.sh)"}
     want = [l.rstrip("\n") for l in open(gold) if l.strip()]
     got = run_vpxdec(hipdec, ivf, md5=True)
+    got_mt = run_vpxdec(mtdec, ivf, md5=True) if os.path.exists(mtdec) else None
+    mt_runs = run_vpxdec(mtdec, ivf, loops=4) if os.path.exists(mtdec) else None
     hip_runs = run_vpxdec(hipdec, ivf, loops=4)   # first loop pays the HIP start-up; report the warm ones
     c_runs = run_vpxdec(cdec, ivf, loops=1)
     warm = hip_runs[1:] or hip_runs
@@ -188,9 +191,12 @@ def stream_leg():
             "md5_frames_equal": sum(a == b for a, b in zip(got, want)), "md5_frames": len(want),
             "md5_match": got == want,
             "vpxdec_hip_fps": round(sum(f for _, f in warm) / len(warm), 2), "vpxdec_hip_fps_first_loop": hip_runs[0][1],
+            "vpxdec_hip_mt_fps": round(sum(f for _, f in mt_runs[1:]) / len(mt_runs[1:]), 2) if mt_runs else None,
+            "vpxdec_hip_mt_md5_match": (got_mt == want) if got_mt is not None else None,
             "vpxdec_c_fps": c_runs[0][1],
             "note": "dx_time-based fps printed by vpxdec --summary (libvpx/vpxdec.c:358-363): whole decode incl. CPU entropy "
-                    "stage, single thread; HIP = patched frame driver (INTEGRATION.md mode C)"}
+                    "stage; vpxdec_c and vpxdec_hip parse on one thread, vpxdec_hip_mt with one thread per tile column (8 here); "
+                    "HIP = patched frame driver (INTEGRATION.md mode C)"}
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -318,7 +318,18 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
     return rc;
   if ((rc = dv_reserve(dec, &S->d_coeffs, sizeof(int32_t) * (size_t)(P->coeff_total + 16)))) return rc;
   S->have_coeffs = dqcoeff != NULL;
-  if (dqcoeff)
+  if (dqcoeff && layout->block_off) {
+    // slots placed by the caller: copy the stretches it names, each to the mirror of its host position
+    for (int64_t r = 0; r < layout->n_regions; ++r) {
+      const vp9hip_coeff_region *g = &layout->regions[r];
+      if (g->plane < 0 || g->plane > 2 || g->start < 0 || g->count < 0 ||
+          layout->plane_base[g->plane] + g->start + g->count > P->coeff_total || !dqcoeff[g->plane])
+        DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: coefficient region %lld out of range", (long long)r);
+      if (g->count)
+        DEC_HIP(dec, hipMemcpyAsync((int32_t *)S->d_coeffs.p + layout->plane_base[g->plane] + g->start, dqcoeff[g->plane] + g->start,
+                                    sizeof(int32_t) * (size_t)g->count, hipMemcpyHostToDevice, cs));
+    }
+  } else if (dqcoeff)
     for (int p = 0; p < 3; ++p)
       if (P->coeff_count[p]) {
         if (!dqcoeff[p]) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: dqcoeff[%d] is null", p);

@@ -722,6 +722,8 @@ static void pk_pass1(void *argp, int tid) {
 
     /* transform blocks: vp9_foreach_transformed_block_in_plane order, clipped to the frame */
     int eobtotal = 0;
+    const uint32_t *boff = (coeffs && coeffs->block_off) ? &coeffs->block_off[3 * (size_t)i] : NULL;
+    int64_t brun[3] = { 0, 0, 0 };
     for (int p = 0; p < 3; ++p) {
       const int s = p ? ss : 0;
       const int n4w = (bw8 * 2) >> s ? (bw8 * 2) >> s : 1, n4h = (bh8 * 2) >> s ? (bh8 * 2) >> s : 1;
@@ -736,6 +738,8 @@ static void pk_pass1(void *argp, int tid) {
           uint32_t off = 0;
           if (!b->skip) {
             off = (uint32_t)(j->coeff_base[p] + run[p]);
+            if (boff) off = (uint32_t)(j->coeff_base[p] + boff[p] + brun[p]);
+            brun[p] += nn;
             run[p] += nn;
             if (coeffs && coeffs->eob[p])
               eob = coeffs->eob[p][(size_t)y * coeffs->eob_stride[p] + x];
@@ -915,6 +919,11 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
   out->coeff_base[2] = coeff_count[0] + coeff_count[1];
   out->coeff_total = coeff_count[0] + coeff_count[1] + coeff_count[2];
   memcpy(out->coeff_count, coeff_count, sizeof(coeff_count));
+  if (coeffs && coeffs->block_off) {
+    /* slots placed by the caller (one region per tile column): offsets come with the blocks */
+    memcpy(out->coeff_base, coeffs->plane_base, sizeof(out->coeff_base));
+    out->coeff_total = coeffs->total;
+  }
   if (out->coeff_total > (int64_t)UINT32_MAX) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: too many coefficients");
   memcpy(j->coeff_base, out->coeff_base, sizeof(j->coeff_base));
 

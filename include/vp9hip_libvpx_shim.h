@@ -48,6 +48,19 @@ void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_
  * same value is free (a caller may issue it for every frame). */
 void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable);
 
+/* Tile-parallel entropy stage (oracle/patch_decodeframe.py --mt, E10).
+ *   vp9hip_shim_run_parallel: fn(arg, 0) .. fn(arg, n - 1) on the shim's persistent thread pool (index 0 on
+ *     the calling thread); returns when all have returned.  VP9HIP_SHIM_THREADS caps the pool (default: n).
+ *   vp9hip_shim_block_off_buffer: a buffer of 3 * n_blocks uint32 the caller fills with, for every block of the
+ *     canonical (decode-order) list, the offset of its coefficient slots inside each plane's array.
+ *   vp9hip_shim_set_tile_layout: the stretches of the coefficient arrays the threads filled — region t, plane p:
+ *     [start[3 * t + p], start[3 * t + p] + count[3 * t + p]) coefficients.  Valid for the frame being decoded;
+ *     the next wrap_cuda_* call consumes it. */
+void vp9hip_shim_run_parallel(struct VP9Decoder *pbi, int n, void (*fn)(void *arg, int index), void *arg);
+#include <stdint.h>
+uint32_t *vp9hip_shim_block_off_buffer(struct VP9Decoder *pbi, int n_blocks);
+void vp9hip_shim_set_tile_layout(struct VP9Decoder *pbi, int n_blocks, int n_regions, const int64_t *start, const int64_t *count);
+
 /* Measurement aid (VP9HIP_SHIM_TRACE=1; a no-op otherwise): marks 0..4 placed in decode_tiles — entry, before
  * the entropy loop, after it, after the two entry points, before return — split a frame's host time into
  * set-up / entropy decode / reconstruction entry points / tear-down in the trace printed at exit. */

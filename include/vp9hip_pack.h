@@ -82,9 +82,28 @@ typedef struct vp9hip_frame_params {
  *   - per plane one array of concatenated N*N blocks in decode order, one slot for EVERY visited
  *     transform block of every non-skip block (also those with eob 0);
  *   - eob[plane][y * eob_stride[plane] + x] at each transform block's top-left sample. */
+/* A used stretch of plane `plane`'s host coefficient array: [start, start + count) coefficients. */
+typedef struct vp9hip_coeff_region {
+  int32_t plane, reserved;
+  int64_t start, count;
+} vp9hip_coeff_region;
+
 typedef struct vp9hip_coeff_layout {
   const int32_t *eob[3];
   int32_t eob_stride[3];
+  int32_t reserved;
+  /* Optional (NULL = the sequential layout above).  block_off[3 * i + p]: where block i's coefficient slots of
+   * plane p start inside plane p's host array, in coefficients — for callers whose entropy stage fills one
+   * region per TILE COLUMN from several threads, so that slots are consecutive per tile, not
+   * per frame.  plane_base[p] is then where plane p's host array is mirrored in the device coefficient
+   * buffer and `total` the size of that buffer (both in coefficients). */
+  const uint32_t *block_off;
+  int64_t plane_base[3];
+  int64_t total;
+  /* with block_off: the stretches of the host arrays that hold this frame's coefficients (what the frame
+   * driver copies to the device, each to plane_base[plane] + start) */
+  const vp9hip_coeff_region *regions;
+  int64_t n_regions;
 } vp9hip_coeff_layout;
 
 typedef struct vp9hip_packed {

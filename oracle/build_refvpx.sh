@@ -15,6 +15,7 @@
 #                                  (`--test-decode=fatal` pins the oracle; also synthesizes test streams)
 #   shim/build/vpxdec_hipA         vpxdec + UNCHANGED frame driver + libvp9hip_shim.so   (PRODUCT, mode A)
 #   shim/build/vpxdec_hip          vpxdec + PATCHED frame driver  + libvp9hip_shim.so   (PRODUCT, mode C)
+#   shim/build/vpxdec_hip_mt       the same + tile-parallel entropy stage (patch_decodeframe.py --mt, E10)
 #
 # What stands between the checked-in headers and a Linux gcc build, and how it is bridged without
 # stand-ins for anything the image lacks:
@@ -65,6 +66,8 @@ gcc -std=gnu99 $CF -include "$OUT/simd_to_c.h" -include "$HERE/ref_decodeframe_p
 TMP="$(mktemp -d)"; trap 'rm -rf "$TMP"' EXIT
 python3 "$HERE/patch_decodeframe.py" "$DF" "$TMP/vp9_decodeframe_patched.c"
 gcc -std=gnu99 $CF -include "$OUT/simd_to_c.h" -include "$HERE/ref_decodeframe_prelude.h" -c "$TMP/vp9_decodeframe_patched.c" -o "$OUT/decodeframe_patched.o"
+python3 "$HERE/patch_decodeframe.py" "$DF" "$TMP/vp9_decodeframe_patched_mt.c" --mt
+gcc -std=gnu99 $CF -include "$OUT/simd_to_c.h" -include "$HERE/ref_decodeframe_prelude.h" -c "$TMP/vp9_decodeframe_patched_mt.c" -o "$OUT/decodeframe_patched_mt.o"
 python3 "$HERE/patch_decodeframe.py" --decoder-c "$L/vp9/decoder/vp9_decoder.c" "$TMP/vp9_decoder_patched.c"
 gcc -std=gnu99 $CF -include "$OUT/simd_to_c.h" -c "$TMP/vp9_decoder_patched.c" -o "$OUT/decoder_patched.o"
 rm -rf "$TMP"
@@ -105,7 +108,9 @@ if [ -f "$ROOT/shim/build/libvp9hip_shim.so" ]; then
       -L"$ROOT/shim/build" -lvp9hip_shim -L"$ROOT/cuda-vp9_amd" -lvp9hip $RP $LINK
   g++ -o "$ROOT/shim/build/vpxdec_hip" $DEC_TOOLS $PATCHED "$OUT/libvpxfull.a" \
       -L"$ROOT/shim/build" -lvp9hip_shim -L"$ROOT/cuda-vp9_amd" -lvp9hip $RP $LINK
-  echo "built shim/build/vpxdec_hipA, vpxdec_hip"
+  g++ -o "$ROOT/shim/build/vpxdec_hip_mt" $DEC_TOOLS "$OUT/decodeframe_patched_mt.o" "$OUT/decoder_patched.o" "$OUT/libvpxfull.a" \
+      -L"$ROOT/shim/build" -lvp9hip_shim -L"$ROOT/cuda-vp9_amd" -lvp9hip $RP $LINK
+  echo "built shim/build/vpxdec_hipA, vpxdec_hip, vpxdec_hip_mt"
 else
   echo "build_refvpx: shim/build/libvp9hip_shim.so absent — run make -C shim first for vpxdec_hip*"
 fi

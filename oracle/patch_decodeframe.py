@@ -30,6 +30,8 @@ Edits (decode_tiles = vp9_decodeframe.c:2303-2639):
       vp9hip_shim_release(pbi): GPU state does not outlive the decoder (`vpxdec --loops=N`)
   E9  vp9hip_shim_mark(pbi, k) at five points of decode_tiles: where the host time of a frame goes, printed
       with VP9HIP_SHIM_TRACE=1 (no effect otherwise)
+  E10 (--mt) tile-parallel entropy stage: one thread per tile column with private list segments /
+      coefficient regions / counts / error trap, merged into the canonical lists afterwards (f2)
   E6  `int n = cm->width * cm->height;` (:2314) sizes dqcoeff[plane] (initBuf :2266) and the block
       lists; coefficient slots cover whole transform blocks, so a frame whose size is not a multiple
       of 8 (or whose last 32x32 transform block overhangs the frame) overruns it (heap corruption,
@@ -56,11 +58,210 @@ def patch_decoder_c(src, dst):
     open(dst, "w", encoding="utf-8", errors="surrogateescape").write(t)
 
 
+MT_CODE = r'''
+/* ---- E10: tile-parallel entropy stage (SURVEY 8f-2) — inserted by oracle/patch_decodeframe.py --mt ---------
+ * One thread per TILE COLUMN walks its tiles top to bottom (tile rows share the above context) with private
+ * cursors: a segment of block-list entries, a region of every plane's coefficient array, its own FRAME_COUNTS
+ * and error trap (as libvpx's tile_worker_hook does, :2663).  Afterwards the segments are merged into the
+ * canonical decode-order lists the entry points take; coefficient slots stay where the threads put them, and
+ * every block's slot offsets go to the shim (vp9hip_shim_set_tile_layout). */
+#include <setjmp.h>
+typedef struct {
+  ModeInfoBuf mb;
+  int *subsize;
+  uint32_t (*coef_off)[3];
+  int n_blocks;
+  int64_t coef_start[3], coef_used[3];
+} vp9hip_tile_seg;
+typedef struct {
+  VP9Decoder *pbi;
+  int tile_rows, tile_cols, sb_cols;
+  frameBuf *fb;
+  int *size_for_mb;
+  vp9hip_tile_seg seg[64];
+} vp9hip_mt_job;
+
+static void vp9hip_parse_tile_col(void *argp, int col) {
+  vp9hip_mt_job *job = (vp9hip_mt_job *)argp;
+  VP9Decoder *const pbi = job->pbi;
+  VP9_COMMON *const cm = &pbi->common;
+  vp9hip_tile_seg *seg = &job->seg[col];
+  frameBuf fb = *job->fb;
+  tran_low_t *dq[3];
+  ModeInfoBuf mb = seg->mb;
+  int *subsize = seg->subsize;
+  TileWorkerData *volatile td = NULL;
+  int p, tile_row, mi_row, mi_col;
+  fb.dqcoeff = dq;
+  for (p = 0; p < 3; ++p) {
+    dq[p] = job->fb->dqcoeff[p] + seg->coef_start[p];
+    vp9hip_tl_coef_base[p] = job->fb->dqcoeff[p];
+  }
+  vp9hip_tl_coef_off = seg->coef_off;
+  vp9hip_tl_block = 0;
+  for (tile_row = 0; tile_row < job->tile_rows; ++tile_row) {
+    TileInfo tile;
+    td = pbi->tile_worker_data + job->tile_cols * tile_row + col;
+    vp9_tile_set_row(&tile, cm, tile_row);
+    vp9_tile_set_col(&tile, cm, col);
+    vp9_zero(td->counts);
+    td->xd.counts = cm->frame_parallel_decoding_mode ? NULL : &td->counts;
+    td->xd.error_info = &td->error_info;
+    td->error_info.setjmp = 1;
+    if (setjmp(td->error_info.jmp)) {
+      td->error_info.setjmp = 0;
+      td->xd.corrupted = 1;
+      break;
+    }
+    for (mi_row = tile.mi_row_start; mi_row < tile.mi_row_end; mi_row += MI_BLOCK_SIZE) {
+      vp9_zero(td->xd.left_context);
+      vp9_zero(td->xd.left_seg_context);
+      for (mi_col = tile.mi_col_start; mi_col < tile.mi_col_end; mi_col += MI_BLOCK_SIZE) {
+        int *cnt = &job->size_for_mb[(mi_row >> 3) * job->sb_cols + (mi_col >> 3)];
+        decode_partition(td, pbi, mi_row, mi_col, BLOCK_64X64, 4, &fb, &mb, cnt, subsize);
+        mb.mi_col += *cnt;
+        mb.mi += *cnt;
+        mb.mi_row += *cnt;
+        mb.bhl += *cnt;
+        mb.bwl += *cnt;
+        subsize += *cnt;
+      }
+    }
+    td->error_info.setjmp = 0;
+  }
+  seg->n_blocks = vp9hip_tl_block;
+  for (p = 0; p < 3; ++p) seg->coef_used[p] = dq[p] - (job->fb->dqcoeff[p] + seg->coef_start[p]);
+  vp9hip_tl_coef_off = NULL;
+}
+
+static void vp9hip_parse_frame_mt(VP9Decoder *pbi, int tile_rows, int tile_cols, frameBuf *frameBuffer, ModeInfoBuf *MiBuf,
+                                  int *size_for_mb, int *subsize_array, int n) {
+  VP9_COMMON *const cm = &pbi->common;
+  const int sb_cols = mi_cols_aligned_to_sb(cm->mi_cols) >> 3, sb_rows = mi_cols_aligned_to_sb(cm->mi_rows) >> 3;
+  const int cap = sb_cols * sb_rows * 64; /* blocks are 8x8 or larger */
+  vp9hip_mt_job *job = (vp9hip_mt_job *)calloc(1, sizeof(*job));
+  MODE_INFO **s_mi = (MODE_INFO **)malloc(sizeof(MODE_INFO *) * cap);
+  int *s_int = (int *)malloc(sizeof(int) * 5 * (size_t)cap);
+  uint32_t(*s_off)[3] = (uint32_t(*)[3])malloc(sizeof(uint32_t) * 3 * (size_t)cap);
+  int64_t start[64][3], used[64][3];
+  int t, p, r, c, total = 0, corrupted = 0;
+  if (!job || !s_mi || !s_int || !s_off) vpx_internal_error(&cm->error, VPX_CODEC_MEM_ERROR, "tile-parallel parse: out of memory");
+  job->pbi = pbi;
+  job->tile_rows = tile_rows;
+  job->tile_cols = tile_cols;
+  job->sb_cols = sb_cols;
+  job->fb = frameBuffer;
+  job->size_for_mb = size_for_mb;
+  for (t = 0; t < tile_cols; ++t) {
+    TileInfo tile;
+    vp9_tile_set_col(&tile, cm, t);
+    {
+      const int first = (tile.mi_col_start >> 3) * sb_rows * 64; /* entries / coefficient share before this tile */
+      vp9hip_tile_seg *seg = &job->seg[t];
+      seg->mb.mi = s_mi + first;
+      seg->mb.mi_row = s_int + first;
+      seg->mb.mi_col = s_int + cap + first;
+      seg->mb.bwl = s_int + 2 * (size_t)cap + first;
+      seg->mb.bhl = s_int + 3 * (size_t)cap + first;
+      seg->subsize = s_int + 4 * (size_t)cap + first;
+      seg->coef_off = s_off + first;
+      for (p = 0; p < 3; ++p) seg->coef_start[p] = (int64_t)(tile.mi_col_start >> 3) * sb_rows * 4096;
+    }
+  }
+  (void)n;
+  vp9hip_shim_run_parallel(pbi, tile_cols, vp9hip_parse_tile_col, job);
+  for (t = 0; t < tile_cols * tile_rows; ++t) corrupted |= pbi->tile_worker_data[t].xd.corrupted;
+  if (!corrupted) {
+    /* merge: superblocks in raster order = the order of the serial loop */
+    int cur[64];
+    uint32_t *block_off;
+    for (t = 0; t < tile_cols; ++t) {
+      cur[t] = 0;
+      total += job->seg[t].n_blocks;
+    }
+    block_off = vp9hip_shim_block_off_buffer(pbi, total);
+    {
+      int k = 0, tcol[256];
+      for (t = 0; t < tile_cols; ++t) {
+        TileInfo tile;
+        vp9_tile_set_col(&tile, cm, t);
+        for (c = tile.mi_col_start >> 3; c < (tile.mi_col_end + 7) >> 3 && c < 256; ++c) tcol[c] = t;
+      }
+      for (r = 0; r < sb_rows; ++r)
+        for (c = 0; c < sb_cols; ++c) {
+          const int cnt = size_for_mb[r * sb_cols + c];
+          vp9hip_tile_seg *seg = &job->seg[tcol[c]];
+          const int a = cur[tcol[c]];
+          memcpy(MiBuf->mi + k, seg->mb.mi + a, sizeof(MODE_INFO *) * cnt);
+          memcpy(MiBuf->mi_row + k, seg->mb.mi_row + a, sizeof(int) * cnt);
+          memcpy(MiBuf->mi_col + k, seg->mb.mi_col + a, sizeof(int) * cnt);
+          memcpy(MiBuf->bwl + k, seg->mb.bwl + a, sizeof(int) * cnt);
+          memcpy(MiBuf->bhl + k, seg->mb.bhl + a, sizeof(int) * cnt);
+          memcpy(subsize_array + k, seg->subsize + a, sizeof(int) * cnt);
+          if (block_off) memcpy(block_off + 3 * (size_t)k, seg->coef_off + a, sizeof(uint32_t) * 3 * cnt);
+          cur[tcol[c]] = a + cnt;
+          k += cnt;
+        }
+    }
+    for (t = 0; t < tile_cols; ++t)
+      for (p = 0; p < 3; ++p) {
+        start[t][p] = job->seg[t].coef_start[p];
+        used[t][p] = job->seg[t].coef_used[p];
+      }
+    vp9hip_shim_set_tile_layout(pbi, total, tile_cols, &start[0][0], &used[0][0]);
+    if (!cm->frame_parallel_decoding_mode)
+      for (t = 0; t < tile_cols * tile_rows; ++t) vp9_accumulate_frame_counts(&cm->counts, &pbi->tile_worker_data[t].counts, 1);
+  }
+  free(s_off);
+  free(s_int);
+  free(s_mi);
+  free(job);
+  if (corrupted) vpx_internal_error(&cm->error, VPX_CODEC_CORRUPT_FRAME, "Failed to decode tile data");
+}
+'''
+
+
+def patch_mt(t):
+    """E10: tile-parallel entropy stage (the serial loop stays for frames with one tile column)."""
+    t = replace_once(t, "#define MAX_VP9_HEADER_SIZE 80\n",
+                     "#define MAX_VP9_HEADER_SIZE 80\n"
+                     "/* E10: where the running tile-column thread records each block's coefficient slot offsets */\n"
+                     "static __thread uint32_t (*vp9hip_tl_coef_off)[3];\n"
+                     "static __thread tran_low_t *vp9hip_tl_coef_base[3];\n"
+                     "static __thread int vp9hip_tl_block;\n", "E10 thread-locals")
+    t = replace_once(t, "  if (!mi->skip) detoken_block(twd, mi, frameBuffer, mi_col, mi_row);\n",
+                     "  if (vp9hip_tl_coef_off) {\n"
+                     "    for (int p_ = 0; p_ < 3; ++p_)\n"
+                     "      vp9hip_tl_coef_off[vp9hip_tl_block][p_] = (uint32_t)(frameBuffer->dqcoeff[p_] - vp9hip_tl_coef_base[p_]);\n"
+                     "    ++vp9hip_tl_block;\n"
+                     "  }\n"
+                     "  if (!mi->skip) detoken_block(twd, mi, frameBuffer, mi_col, mi_row);\n", "E10 decode_block")
+    t = replace_once(t, "static const uint8_t *decode_tiles(VP9Decoder *pbi, const uint8_t *data, const uint8_t *data_end) {",
+                     MT_CODE + "\nstatic const uint8_t *decode_tiles(VP9Decoder *pbi, const uint8_t *data, const uint8_t *data_end) {",
+                     "E10 helper insertion")
+    a = t.find("  //entropy decoder\n")
+    b = t.find("  //go to start\n", a)
+    if a < 0 or b < 0:
+        sys.exit("patch_decodeframe: anchor not found: E10 entropy loop")
+    loop = t[a + len("  //entropy decoder\n"):b]
+    if loop.count("decode_partition(tile_data, pbi, mi_row, mi_col, BLOCK_64X64, 4, frameBuffer, &MiBuf, size_for_mb, subsize_array);") != 1:
+        sys.exit("patch_decodeframe: E10 range does not look like the entropy loop")
+    marks = ""
+    if loop.rstrip().endswith("vp9hip_shim_mark(pbi, 2);"):
+        loop = loop[:loop.rstrip().rfind("vp9hip_shim_mark(pbi, 2);")]
+        marks = "  vp9hip_shim_mark(pbi, 2);\n"
+    t = (t[:a] + "  //entropy decoder\n  if (tile_cols > 1 && pbi->row_mt != 1 && !pbi->inv_tile_order) {\n"
+         "    vp9hip_parse_frame_mt(pbi, tile_rows, tile_cols, frameBuffer, &MiBuf, size_for_mb, subsize_array, n);\n"
+         "  } else {\n" + loop + "  }\n" + marks + t[b:])
+    return t
+
+
 def main():
     if sys.argv[1] == "--decoder-c":
         return patch_decoder_c(sys.argv[2], sys.argv[3])
     src, dst = sys.argv[1], sys.argv[2]
     gpu_lf = "--keep-cpu-loop-filter" not in sys.argv[3:]
+    mt = "--mt" in sys.argv[3:]
     t = open(src, encoding="utf-8", errors="surrogateescape").read()
 
     # E1
@@ -128,6 +329,8 @@ def main():
     t = replace_once(t, "    X_Fuel(pbi);\n",
                      "    if (get_frame_new_buffer(&pbi->common)->flags & YV12_FLAG_HIGHBITDEPTH) X_Fuel(pbi);\n", "E5 X_Fuel")
 
+    if mt:
+        t = patch_mt(t)
     open(dst, "w", encoding="utf-8", errors="surrogateescape").write(t)
 
 

@@ -137,6 +137,12 @@ void *vp9hip_shim_frame_memory(struct VP9Common *cm, int which, size_t bytes) {
   return NULL;
 }
 
+/* the tile-parallel hooks exist for the shim only; the oracle is linked with the serial driver */
+void vp9hip_shim_run_parallel(struct VP9Decoder *pbi, int n, void (*fn)(void *arg, int index), void *arg) {
+  (void)pbi;
+  for (int i = 0; i < n; ++i) fn(arg, i);
+}
+
 void vp9hip_shim_mark(struct VP9Decoder *pbi, int mark) {
   (void)pbi;
   (void)mark;

@@ -67,6 +67,12 @@ typedef struct {
   /* page-locked memory lent to the caller's initBuf (vp9hip_shim_frame_memory): 0..2 coefficient arrays, 3 eob plane */
   void *frame_mem[4];
   size_t frame_mem_cap[4];
+  size_t frame_mem_req[4]; /* bytes the caller asked for last */
+  /* tile-parallel entropy stage: per-block coefficient offsets + the filled regions of this frame */
+  uint32_t *block_off;
+  int block_off_cap, tile_layout_blocks;
+  vp9hip_coeff_region regions[64 * 3];
+  int n_regions;
   int creating;
   int gpu_lf;
   struct {
@@ -172,6 +178,7 @@ void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_
   shim_state *s = state_of(pbi, &pbi->common);
   if (!s) return;
   s->attached = frameBuffer;
+  s->tile_layout_blocks = -1; /* a new frame: any tile layout belongs to the previous one */
   if (frameBuffer)
     for (int p = 0; p < 3; ++p) s->dq_start[p] = frameBuffer->dqcoeff[p];
 }
@@ -181,6 +188,7 @@ void *vp9hip_shim_frame_memory(struct VP9Common *cm, int which, size_t bytes) {
   VP9Decoder *pbi = (VP9Decoder *)((char *)cm - offsetof(VP9Decoder, common));
   shim_state *s = state_of(pbi, cm);
   if (!s || which < 0 || which > 3) return NULL;
+  s->frame_mem_req[which] = bytes;
   if (bytes > s->frame_mem_cap[which]) {
     /* nothing of an earlier frame is in flight here: the intra wrapper synchronised before it returned */
     vp9hip_decoder_host_free(s->dec, s->frame_mem[which]);
@@ -193,6 +201,107 @@ void *vp9hip_shim_frame_memory(struct VP9Common *cm, int which, size_t bytes) {
     s->frame_mem_cap[which] = bytes + bytes / 8;
   }
   return s->frame_mem[which];
+}
+
+/* ---- tile-parallel entropy stage --------------------------------------------------------------------- */
+#define SHIM_POOL_MAX 64
+static struct {
+  pthread_mutex_t mu;
+  pthread_cond_t go, done;
+  pthread_t th[SHIM_POOL_MAX];
+  int n_threads, pending, next, n_items;
+  unsigned gen;
+  void (*fn)(void *, int);
+  void *arg;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
+
+static void *pool_worker(void *unused) {
+  unsigned seen = 0;
+  (void)unused;
+  pthread_mutex_lock(&g_pool.mu);
+  for (;;) {
+    while (g_pool.gen == seen) pthread_cond_wait(&g_pool.go, &g_pool.mu);
+    seen = g_pool.gen;
+    while (g_pool.next < g_pool.n_items) {
+      const int i = g_pool.next++;
+      void (*fn)(void *, int) = g_pool.fn;
+      void *arg = g_pool.arg;
+      pthread_mutex_unlock(&g_pool.mu);
+      fn(arg, i);
+      pthread_mutex_lock(&g_pool.mu);
+      if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.done);
+    }
+  }
+  return NULL;
+}
+
+void vp9hip_shim_run_parallel(struct VP9Decoder *pbi, int n, void (*fn)(void *arg, int index), void *arg) {
+  (void)pbi;
+  if (n <= 0) return;
+  int want = n - 1;
+  const char *e = getenv("VP9HIP_SHIM_THREADS");
+  if (e && atoi(e) - 1 < want) want = atoi(e) - 1;
+  if (want > SHIM_POOL_MAX) want = SHIM_POOL_MAX;
+  pthread_mutex_lock(&g_pool.mu);
+  while (g_pool.n_threads < want) {
+    if (pthread_create(&g_pool.th[g_pool.n_threads], NULL, pool_worker, NULL)) break;
+    ++g_pool.n_threads;
+  }
+  if (g_pool.n_threads == 0 || want <= 0) {
+    pthread_mutex_unlock(&g_pool.mu);
+    for (int i = 0; i < n; ++i) fn(arg, i);
+    return;
+  }
+  g_pool.fn = fn;
+  g_pool.arg = arg;
+  g_pool.n_items = n;
+  g_pool.next = 0;
+  g_pool.pending = n;
+  ++g_pool.gen;
+  pthread_cond_broadcast(&g_pool.go);
+  /* the caller works too */
+  while (g_pool.next < g_pool.n_items) {
+    const int i = g_pool.next++;
+    pthread_mutex_unlock(&g_pool.mu);
+    fn(arg, i);
+    pthread_mutex_lock(&g_pool.mu);
+    --g_pool.pending;
+  }
+  while (g_pool.pending) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+  pthread_mutex_unlock(&g_pool.mu);
+}
+
+uint32_t *vp9hip_shim_block_off_buffer(struct VP9Decoder *pbi, int n_blocks) {
+  shim_state *s = state_of(pbi, &pbi->common);
+  if (!s) return NULL;
+  if (n_blocks > s->block_off_cap) {
+    free(s->block_off);
+    s->block_off_cap = n_blocks + n_blocks / 4 + 256;
+    s->block_off = (uint32_t *)malloc(sizeof(uint32_t) * 3 * (size_t)s->block_off_cap);
+    if (!s->block_off) {
+      s->block_off_cap = 0;
+      vpx_internal_error(&pbi->common.error, VPX_CODEC_MEM_ERROR, "vp9hip shim: out of memory");
+      return NULL;
+    }
+  }
+  return s->block_off;
+}
+
+void vp9hip_shim_set_tile_layout(struct VP9Decoder *pbi, int n_blocks, int n_regions, const int64_t *start, const int64_t *count) {
+  shim_state *s = state_of(pbi, &pbi->common);
+  if (!s) return;
+  s->tile_layout_blocks = -1;
+  if (n_regions < 0 || n_regions > 64 || n_blocks < 0 || n_blocks > s->block_off_cap) return;
+  s->n_regions = 0;
+  for (int t = 0; t < n_regions; ++t)
+    for (int p = 0; p < 3; ++p) {
+      vp9hip_coeff_region *g = &s->regions[s->n_regions++];
+      g->plane = p;
+      g->reserved = 0;
+      g->start = start[3 * t + p];
+      g->count = count[3 * t + p];
+    }
+  s->tile_layout_blocks = n_blocks;
 }
 
 void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable) {
@@ -218,6 +327,7 @@ void vp9hip_shim_release(struct VP9Decoder *pbi) {
   for (int k = 0; k < 4; ++k) vp9hip_decoder_host_free(old.dec, old.frame_mem[k]);
   vp9hip_decoder_destroy(old.dec);
   free(old.blocks);
+  free(old.block_off);
 }
 
 #define SHIM_CHECK(s, cm, expr)                                                                        \
@@ -377,6 +487,26 @@ static int begin_frame(shim_state *s, VP9_COMMON *cm, VP9Decoder *pbi, int *size
     }
     /* coefficient arrays the caller got from vp9hip_shim_frame_memory are page-locked and stay untouched
      * until the frame has been delivered: they travel asynchronously */
+    memset(&L.reserved, 0, sizeof(L) - offsetof(vp9hip_coeff_layout, reserved));
+    if (s->tile_layout_blocks >= 0) {
+      /* the entropy stage ran one thread per tile column: slots are consecutive per tile (E10) */
+      if (s->tile_layout_blocks != n) {
+        s->tile_layout_blocks = -1;
+        vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: tile layout describes %d blocks, the list has %d",
+                           s->tile_layout_blocks, n);
+        return -1;
+      }
+      L.block_off = s->block_off;
+      int64_t base = 0;
+      for (int p = 0; p < 3; ++p) {
+        L.plane_base[p] = base;
+        base += (int64_t)(s->frame_mem_req[p] / sizeof(int32_t));
+      }
+      L.total = base;
+      L.regions = s->regions;
+      L.n_regions = s->n_regions;
+      s->tile_layout_blocks = -1; /* consumed */
+    }
     const int persistent = s->frame_mem[0] && dq[0] == (const int32_t *)s->frame_mem[0] && dq[1] == (const int32_t *)s->frame_mem[1] &&
                            dq[2] == (const int32_t *)s->frame_mem[2];
     SHIM_CHECK(s, cm, vp9hip_decoder_begin_frame_ex(s->dec, &P, s->blocks, n, &L, dq, persistent ? VP9HIP_BEGIN_HOST_PERSISTENT : 0));

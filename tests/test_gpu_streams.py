@@ -6,6 +6,9 @@ must equal the list the same vpxdec produced with the CPU wrap_cuda_* bodies of 
 
   vpxdec_hip   patched frame driver (oracle/patch_decodeframe.py = INTEGRATION.md mode C): inverse
                transforms, prediction and loop filter on the GPU, references resident in HBM
+  vpxdec_hip_mt  the patched driver with the entropy stage run by one thread per tile column
+               (patch_decodeframe.py --mt, E10: private list segments / coefficient regions per tile column,
+               merged into the canonical lists)
   vpxdec_hipA  UNCHANGED reference frame driver (mode A: its CPU transforms left int64 residual planes,
                its CPU loop filter runs afterwards) — high-bitdepth streams only, like the reference
 
@@ -22,6 +25,7 @@ SMALL = os.path.join(ROOT, "tests", "golden", "streams")
 BIG = os.path.join(ROOT, "tests", "streams_big")
 HIP = os.path.join(ROOT, "shim", "build", "vpxdec_hip")
 HIP_A = os.path.join(ROOT, "shim", "build", "vpxdec_hipA")
+HIP_MT = os.path.join(ROOT, "shim", "build", "vpxdec_hip_mt")
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +60,18 @@ def test_stream_md5_patched_driver(name):
     check(HIP, SMALL, name)
 
 
+@pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444"])
+def test_stream_md5_tile_parallel_entropy_stage(name):
+    # s704_8 / s704_10 have two tile columns; the others take the driver's serial loop
+    check(HIP_MT, SMALL, name)
+
+
+def test_tile_parallel_result_does_not_depend_on_the_thread_count():
+    want = golden(os.path.join(SMALL, "s704_8.md5"))
+    for threads in ("1", "2", "5"):
+        assert md5_lines(HIP_MT, os.path.join(SMALL, "s704_8.ivf"), env={"VP9HIP_SHIM_THREADS": threads}) == want
+
+
 def test_stream_md5_unchanged_reference_driver():
     # profile 2, 704x576: what the reference's decode_tiles can run as it is
     check(HIP_A, SMALL, "s704_10")
@@ -66,3 +82,4 @@ def test_baseline_sized_stream_md5(name):
     if not os.path.exists(os.path.join(BIG, name + ".ivf")):
         pytest.skip(f"tests/streams_big/{name}.ivf not generated (make_streams.py --big)")
     check(HIP, BIG, name)
+    check(HIP_MT, BIG, name)  # 8 / 8 / 16 tile columns
