@@ -9,8 +9,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/tools/profile_phase.py --phase all --steps 6 --no-overlap"
-TRACE_CMD="python3 $ROOT/tools/profile_phase.py --phase all --steps 6"
+CMD="python3 $ROOT/tools/profile_phase.py --steps 6 --separate"
+TRACE_CMD="python3 $ROOT/tools/profile_phase.py --steps 20 --separate"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq -o sq -- $CMD > $OUT/sq.log 2>&1

@@ -6,10 +6,26 @@ and the doubled figure are given), LDS bank-conflict rate and the wave-time spli
     python3 tools/pmc_summary.py gpurun_out/pmc_<tag> profiles/<name>.json"""
 import collections
 import csv
+import datetime
 import glob
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the kernel sources a family's record belongs to (bench.py quotes a record only while this hash matches)
+SOURCES = {"convolve": ["inter_kernels.hip"], "idct_add": ["txfm_kernels.hip", "txfm_device.h"],
+           "intra": ["intra_kernels.hip", "txfm_device.h"], "intra_residual": ["intra_kernels.hip", "txfm_device.h"],
+           "loop_filter": ["lf_kernels.hip"]}
+
+
+def source_hash(files):
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "cuda-vp9_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 FAMILY = (("inter_fast_kernel", "convolve"), ("inter_fast16_kernel", "convolve"), ("inter_reg_kernel", "convolve"), ("inter_pred_kernel", "convolve_generic"), ("idct_add", "idct_add"),
           ("intra_island_kernel", "intra"), ("intra_residual_kernel", "intra_residual"), ("intra_wave_kernel", "intra_waves"), ("lf_rows", "loop_filter"),
@@ -61,6 +77,9 @@ def main(src, dst):
                                     (("waiting", "SQ_WAIT_ANY"), ("issue_stall", "SQ_WAIT_INST_ANY"), ("issuing", "SQ_ACTIVE_INST_ANY"))}
         if m.get("TCC_HIT_sum") is not None and (m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)) > 0:
             e["l2_hit_rate"] = round(m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 3)
+        if fam in SOURCES:
+            e["source_sha256"] = source_hash(SOURCES[fam])
+        e["collected"] = datetime.date.today().isoformat() + " tools/pmc_collect.sh (blockgen 1440p frame, phases in separate runs)"
         out[fam] = e
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters_mean_per_launch"} for k, v in out.items()}, indent=1))
