@@ -167,6 +167,7 @@ class Decoder:
         L.vp9hip_decoder_begin_frame.argtypes = [vp, ctypes.POINTER(FrameParams), vp, ctypes.c_int,
                                                  ctypes.POINTER(CoeffLayout), ctypes.POINTER(vp * 3)]
         L.vp9hip_decoder_begin_frame_ex.argtypes = L.vp9hip_decoder_begin_frame.argtypes + [ctypes.c_int]
+        L.vp9hip_decoder_set_timing.argtypes = [vp, ctypes.c_int]
         L.vp9hip_decoder_current_set.argtypes = [vp]
         L.vp9hip_decoder_select_set.argtypes = [vp, ctypes.c_int]
         L.vp9hip_decoder_host_alloc.argtypes = [vp, ctypes.c_size_t]
@@ -237,6 +238,9 @@ class Decoder:
                                                        ctypes.byref(cl) if cl is not None else None,
                                                        ctypes.byref(dq) if dq is not None else None, int(bool(persistent))))
         return lib().vp9hip_decoder_current_set(self.handle)
+
+    def set_timing(self, on):
+        self.check(lib().vp9hip_decoder_set_timing(self.handle, int(bool(on))))
 
     def select_set(self, ring_set):
         self.check(lib().vp9hip_decoder_select_set(self.handle, ring_set))

@@ -574,14 +574,14 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task
 // __syncthreads() orders the global stores of one wave before the edge loads of the next for
 // the threads of this workgroup (same CU, same L1).
 template <typename Pix, bool HBD, bool RES>
-__global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_task *__restrict__ tasks,
-                                                           const vp9hip_intra_island *__restrict__ islands,
-                                                           const int32_t *__restrict__ wave_off,
-                                                           const int32_t *__restrict__ coeffs, ResidDev rd, FrameDev f,
-                                                           int *__restrict__ sb_done, int sb_cols) {
+__device__ __forceinline__ void intra_island_body(const vp9hip_intra_task *__restrict__ tasks,
+                                                  const vp9hip_intra_island *__restrict__ islands,
+                                                  const int32_t *__restrict__ wave_off, const int32_t *__restrict__ coeffs,
+                                                  const ResidDev &rd, const FrameDev &f, int *__restrict__ sb_done, int sb_cols,
+                                                  int island) {
   __shared__ int edge[SLOTS][ESIZE];
   __shared__ int tiles[RES ? 1 : SLOTS][RES ? 1 : 32 * TPITCH];
-  const vp9hip_intra_island isl = islands[blockIdx.x];
+  const vp9hip_intra_island isl = islands[island];
   // The two slots of a wavefront run their blocks one after the other wherever the blocks differ (size,
   // mode), and most waves of a deep chain have four tasks or fewer: task j of a chunk goes to wavefront
   // j % 4 (slot 2 * (j % 4) + j / 4), so that up to four tasks get a wavefront each.  With slot = task the
@@ -628,8 +628,18 @@ __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_ta
   }
 }
 
+template <typename Pix, bool HBD, bool RES>
+__global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_task *__restrict__ tasks,
+                                                           const vp9hip_intra_island *__restrict__ islands,
+                                                           const int32_t *__restrict__ wave_off,
+                                                           const int32_t *__restrict__ coeffs, ResidDev rd, FrameDev f,
+                                                           int *__restrict__ sb_done, int sb_cols) {
+  intra_island_body<Pix, HBD, RES>(tasks, islands, wave_off, coeffs, rd, f, sb_done, sb_cols, (int)blockIdx.x);
+}
+
 }  // namespace
 
+#ifndef VP9HIP_INTRA_DEVICE_ONLY  // lf_kernels.hip includes this file for the device code above (fused walk + filter)
 // Residual scratch of the context: one int32 per sample of the frame, planes back to back.  Growing it
 // synchronises, so callers that fork streams make sure of it first.
 int vp9hip_ensure_resid(vp9hip_ctx *ctx, const vp9hip_frame *frame) {
@@ -645,6 +655,8 @@ int vp9hip_ensure_resid(vp9hip_ctx *ctx, const vp9hip_frame *frame) {
   return VP9HIP_OK;
 }
 
+#endif  // !VP9HIP_INTRA_DEVICE_ONLY
+
 static ResidDev resid_dev(vp9hip_ctx *ctx, const vp9hip_frame *frame) {
   ResidDev rd;
   memset(&rd, 0, sizeof(rd));
@@ -657,6 +669,8 @@ static ResidDev resid_dev(vp9hip_ctx *ctx, const vp9hip_frame *frame) {
   }
   return rd;
 }
+
+#ifndef VP9HIP_INTRA_DEVICE_ONLY
 
 static int residual_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
                            const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
@@ -710,17 +724,15 @@ extern "C" int vp9hip_intra_residual_begin(vp9hip_ctx *ctx, const vp9hip_intra_t
   return VP9HIP_OK;
 }
 
-int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
-                          const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
-                          const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_sb_done, int sb_cols) {
-  const FrameDev f = to_dev(frame);
-  ResidDev rd;
-  memset(&rd, 0, sizeof(rd));
+// The residual of the island tasks on stream `st`: the pre-pass vp9hip_intra_residual_begin started for these
+// lists is waited for, or it is run now.  After this the island walk of the lists may be enqueued on `st`.
+int vp9hip_islands_prepare(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
+                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
+                           const int32_t *d_coeffs, const vp9hip_frame *frame) {
   if (d_coeffs) {
     // the inverse transforms of every coded task, in parallel, ahead of the dependent walk
     int rc = vp9hip_ensure_resid(ctx, frame);
     if (rc) return rc;
-    rd = resid_dev(ctx, frame);
     if (ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs) {
       VP9HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_resid_done, 0));  // vp9hip_intra_residual_begin did it
     } else {
@@ -729,6 +741,18 @@ int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_ta
     }
   }
   ctx->resid_tasks = nullptr;
+  return VP9HIP_OK;
+}
+
+int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
+                          const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
+                          const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_sb_done, int sb_cols) {
+  const FrameDev f = to_dev(frame);
+  ResidDev rd;
+  memset(&rd, 0, sizeof(rd));
+  int rc = vp9hip_islands_prepare(ctx, st, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
+  if (rc) return rc;
+  if (d_coeffs) rd = resid_dev(ctx, frame);
   if (frame->hbd)
     hipLaunchKernelGGL((intra_island_kernel<uint16_t, true, true>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
                        d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);
@@ -773,3 +797,4 @@ extern "C" int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task 
   VP9HIP_CHECK(ctx, hipGetLastError());
   return VP9HIP_OK;
 }
+#endif  // !VP9HIP_INTRA_DEVICE_ONLY

@@ -23,6 +23,11 @@
 
 #include "vp9hip_internal.h"
 
+// the island walk's device code, for the fused walk + filter kernel below
+#define VP9HIP_INTRA_DEVICE_ONLY
+#include "intra_kernels.hip"
+#undef VP9HIP_INTRA_DEVICE_ONLY
+
 namespace {
 
 struct LfThreshDev {
@@ -791,6 +796,40 @@ __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restr
                           gate_done, gate_expected, sb_rows);
 }
 
+// The island walk and the loop filter of a frame as ONE launch: workgroups [0, sb_rows * planes) are the
+// filter's rows (dispatched first, so they are resident before the islands flood the GPU: a filter row
+// waits, bounded, for islands, and islands never wait for anything), the rest walk one island each.  No
+// second stream, no fork / join events between the transforms, this pair and the next frame's convolve —
+// every such dependency packet cost the command processor several microseconds between two kernels
+// (rocprofv3 trace of bench.py, DESIGN.md §3.4: 12 us before and 37 us after the pair as two launches).
+template <typename Pix, int SH>
+__global__ __launch_bounds__(256) void walk_lf_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows, int planes,
+                                                      LfThreshDev th, FrameDev f, int mi_rows, int *progress, int *err,
+                                                      int *gate_done, const int *gate_expected,
+                                                      const vp9hip_intra_task *__restrict__ tasks,
+                                                      const vp9hip_intra_island *__restrict__ islands,
+                                                      const int32_t *__restrict__ wave_off, ResidDev rd) {
+  const int n_lf = sb_rows * planes;
+  if ((int)blockIdx.x >= n_lf) {
+    intra_island_body<Pix, sizeof(Pix) == 2, true>(tasks, islands, wave_off, nullptr, rd, f, gate_done, sb_cols,
+                                                   (int)blockIdx.x - n_lf);
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
+  __shared__ unsigned ctls[2 * 256];
+  __shared__ unsigned flags[2];
+  const int sr = (int)blockIdx.x % sb_rows, pl = (int)blockIdx.x / sb_rows;
+  int *hprev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
+  int *hmine = progress + pl * sb_rows + sr;
+  int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
+  if (pl == 0 || f.awidth[pl] == f.awidth[0])
+    lf_row2_body<Pix, 64, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
+                              gate_done, gate_expected, sb_rows);
+  else
+    lf_row2_body<Pix, 32, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
+                              gate_done, gate_expected, sb_rows);
+}
+
 template <typename Pix>
 __global__ __launch_bounds__(64) void lf_rows_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                                      LfThreshDev th, FrameDev f, int mi_rows, int *progress,
@@ -959,6 +998,51 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
     if (rc) return rc;
   }
   int *d_gate = (int *)ctx->scratch + gate_off;
+  static int two_streams = -1;  // VP9HIP_LF_TWO_STREAMS=1: the earlier form (walk and filter as two launches on two streams)
+  if (two_streams < 0) two_streams = getenv("VP9HIP_LF_TWO_STREAMS") != nullptr;
+  if (!two_streams && d_coeffs) {
+    // ---- one launch for both (walk_lf_kernel) ------------------------------------------------------
+    const bool zeroed1 = ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs && ctx->lf_zeroed_rows == sb_rows &&
+                         ctx->lf_zeroed_cols == sb_cols;
+    ctx->lf_zeroed_rows = ctx->lf_zeroed_cols = 0;
+    if (!zeroed1) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
+    int rc1 = vp9hip_islands_prepare(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
+    if (rc1) return rc1;
+    if (!d_lfm || !h_thresh || (planes != 1 && planes != 3)) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: bad argument");
+    if (sb_rows != (frame->aheight[0] + 63) / 64 || sb_cols != (frame->awidth[0] + 63) / 64)
+      VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: %dx%d superblocks do not cover a %dx%d frame", sb_cols, sb_rows,
+                  frame->awidth[0], frame->aheight[0]);
+    {
+      const bool c420 = frame->awidth[1] * 2 == frame->awidth[0] && frame->aheight[1] * 2 == frame->aheight[0];
+      const bool c444 = frame->awidth[1] == frame->awidth[0] && frame->aheight[1] == frame->aheight[0];
+      if (planes == 3 && !c420 && !c444) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: chroma must be 4:2:0 or 4:4:4");
+    }
+    if (!ctx->lf_err_flag) {
+      VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_err_flag, sizeof(int)));
+      VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(int)));
+    }
+    ctx->lf_err_armed = true;
+    LfThreshDev th;
+    memcpy(&th, h_thresh, sizeof(th));
+    const FrameDev f = to_dev(frame);
+    const ResidDev rd = resid_dev(ctx, frame);
+    const int grid = sb_rows * planes + n_islands;
+#define WALK_LF(PIX, SH)                                                                                              \
+  hipLaunchKernelGGL((walk_lf_kernel<PIX, SH>), dim3(grid), dim3(256), 0, ctx->stream, d_lfm, sb_cols, sb_rows, planes, th, f, \
+                     frame->aheight[0] / 8, (int *)ctx->scratch, ctx->lf_err_flag, d_gate, d_sb_expected, d_tasks, d_islands, \
+                     d_wave_off, rd)
+    if (!frame->hbd)
+      WALK_LF(uint8_t, 0);
+    else if (frame->bit_depth == 10)
+      WALK_LF(uint16_t, 2);
+    else if (frame->bit_depth == 12)
+      WALK_LF(uint16_t, 4);
+    else
+      WALK_LF(uint16_t, 0);
+#undef WALK_LF
+    VP9HIP_CHECK(ctx, hipGetLastError());
+    return VP9HIP_OK;
+  }
   // the counters were zero-filled by vp9hip_intra_residual_begin of this frame (on stream2, which the filter
   // follows in order and the walk waits for), or are now
   const bool zeroed = d_coeffs && ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs &&

@@ -48,6 +48,7 @@ struct vp9hip_decoder {
   int32_t res_stride[3];
   bool have_res;
   bool timed;
+  bool timing_off;  // vp9hip_decoder_set_timing(dec, 0): no event pair around a run
 };
 
 #define DEC_FAIL(dec, code, ...)                              \
@@ -459,8 +460,11 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
   dec->ctx->resid_tasks = nullptr;
   dec->ctx->resid_coeffs = nullptr;
   dec->ctx->lf_zeroed_rows = dec->ctx->lf_zeroed_cols = 0;
-  DEC_HIP(dec, hipStreamWaitEvent(st, S->uploaded, 0));
-  DEC_CTX(dec, vp9hip_timer_begin(dec->ctx, TIMER_RUN));
+  // lists + coefficients: usually long in HBM when a replayed or pipelined frame is run — then no
+  // dependency packet goes into the queue (every marker / barrier packet costs the command processor
+  // microseconds between two kernels)
+  if (hipEventQuery(S->uploaded) != hipSuccess) DEC_HIP(dec, hipStreamWaitEvent(st, S->uploaded, 0));
+  if (!dec->timing_off) DEC_CTX(dec, vp9hip_timer_begin(dec->ctx, TIMER_RUN));
 
   // coefficient mode: the island tasks' inverse transforms only need the coefficients — they start beside
   // the convolve and the inter transforms (in residual-plane mode the residual is gathered later)
@@ -563,10 +567,17 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
     DEC_CTX(dec, vp9hip_loop_filter_frame(dec->ctx, (const vp9hip_lfm *)S->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
                                           3));
   }
-  DEC_CTX(dec, vp9hip_timer_end(dec->ctx, TIMER_RUN));
+  if (!dec->timing_off) DEC_CTX(dec, vp9hip_timer_end(dec->ctx, TIMER_RUN));
   DEC_HIP(dec, hipEventRecord(S->done, st));
   S->done_pending = true;
-  dec->timed = true;
+  dec->timed = !dec->timing_off;
+  return VP9HIP_OK;
+}
+
+extern "C" int vp9hip_decoder_set_timing(vp9hip_decoder *dec, int on) {
+  if (!dec) return VP9HIP_EINVAL;
+  dec->timing_off = !on;
+  if (!on) dec->timed = false;
   return VP9HIP_OK;
 }
 

@@ -86,6 +86,9 @@ static inline int frame_ok(const vp9hip_frame *f) {
 int vp9hip_ensure_scratch(vp9hip_ctx *ctx, size_t bytes);
 int vp9hip_ensure_resid(vp9hip_ctx *ctx, const vp9hip_frame *frame);
 int vp9hip_lf_zero_counters(vp9hip_ctx *ctx, const vp9hip_frame *frame, hipStream_t st);
+int vp9hip_islands_prepare(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
+                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
+                           const int32_t *d_coeffs, const vp9hip_frame *frame);
 int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
                           const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_sb_done, int sb_cols);

@@ -101,6 +101,9 @@ int vp9hip_decoder_set_residual_planes(vp9hip_decoder *dec, const int64_t *const
 int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref_slot[3], int dst_slot,
                        const vp9hip_lfm *h_lfm, const vp9hip_lf_thresh *thresh);
 int vp9hip_decoder_sync(vp9hip_decoder *dec);
+/* The event pair that times a run is on by default; a caller that never reads vp9hip_decoder_last_run_ms can
+ * switch it off (two packets less in the queue per frame). */
+int vp9hip_decoder_set_timing(vp9hip_decoder *dec, int on);
 /* GPU milliseconds of the kernels enqueued by the last vp9hip_decoder_run (after a sync). */
 int vp9hip_decoder_last_run_ms(vp9hip_decoder *dec, float *ms);
 /* Work lists of the frame begun last (host copies owned by the decoder; for tests). */
