@@ -808,11 +808,23 @@ __global__ __launch_bounds__(256) void walk_lf_kernel(const vp9hip_lfm *__restri
                                                       int *gate_done, const int *gate_expected,
                                                       const vp9hip_intra_task *__restrict__ tasks,
                                                       const vp9hip_intra_island *__restrict__ islands,
-                                                      const int32_t *__restrict__ wave_off, ResidDev rd) {
+                                                      const int32_t *__restrict__ wave_off, ResidDev rd,
+                                                      const int32_t *__restrict__ coeffs) {
   const int n_lf = sb_rows * planes;
   if ((int)blockIdx.x >= n_lf) {
-    intra_island_body<Pix, sizeof(Pix) == 2, true>(tasks, islands, wave_off, nullptr, rd, f, gate_done, sb_cols,
-                                                   (int)blockIdx.x - n_lf);
+    const int island = (int)blockIdx.x - n_lf;
+    if (coeffs != nullptr) {
+      // the residual of the island's coded tasks first (no waves: every task at once, eight at a time), into
+      // the residual scratch the walk then adds from — what intra_residual_kernel does as a launch of its own
+      __shared__ int rtiles[SLOTS][32 * TPITCH];
+      const vp9hip_intra_island isl = islands[island];
+      const int n = wave_off[isl.wave_off_start + isl.n_waves];
+      const int slot = threadIdx.x / SLOT;
+      for (int base = 0; base < n; base += SLOTS)
+        residual_chunk<sizeof(Pix) == 2>(rtiles, tasks, isl.task_start + base + slot, base + slot < n, coeffs, rd, f);
+      __syncthreads();
+    }
+    intra_island_body<Pix, sizeof(Pix) == 2, true>(tasks, islands, wave_off, nullptr, rd, f, gate_done, sb_cols, island);
     return;
   }
   __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
@@ -1006,8 +1018,18 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
                          ctx->lf_zeroed_cols == sb_cols;
     ctx->lf_zeroed_rows = ctx->lf_zeroed_cols = 0;
     if (!zeroed1) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
-    int rc1 = vp9hip_islands_prepare(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
-    if (rc1) return rc1;
+    // VP9HIP_FUSED_RESIDUAL=1: the island workgroups also run their tasks' inverse transforms (no pre-pass launch,
+    // no second stream at all).  Measured on the bench frame: one stream 2012 against 2060 frames/s with the
+    // pre-pass beside the convolve, eight streams in flight 3640 against 3075 — the default serves one stream.
+    static int own_resid = -1;
+    if (own_resid < 0) own_resid = getenv("VP9HIP_FUSED_RESIDUAL") != nullptr;
+    const bool prepass_done = ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs;
+    const int32_t *k_coeffs = (own_resid && !prepass_done) ? d_coeffs : nullptr;
+    if (!k_coeffs) {
+      int rc1 = vp9hip_islands_prepare(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
+      if (rc1) return rc1;
+    }
+    ctx->resid_tasks = nullptr;
     if (!d_lfm || !h_thresh || (planes != 1 && planes != 3)) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: bad argument");
     if (sb_rows != (frame->aheight[0] + 63) / 64 || sb_cols != (frame->awidth[0] + 63) / 64)
       VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: %dx%d superblocks do not cover a %dx%d frame", sb_cols, sb_rows,
@@ -1030,7 +1052,7 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
 #define WALK_LF(PIX, SH)                                                                                              \
   hipLaunchKernelGGL((walk_lf_kernel<PIX, SH>), dim3(grid), dim3(256), 0, ctx->stream, d_lfm, sb_cols, sb_rows, planes, th, f, \
                      frame->aheight[0] / 8, (int *)ctx->scratch, ctx->lf_err_flag, d_gate, d_sb_expected, d_tasks, d_islands, \
-                     d_wave_off, rd)
+                     d_wave_off, rd, k_coeffs)
     if (!frame->hbd)
       WALK_LF(uint8_t, 0);
     else if (frame->bit_depth == 10)

@@ -468,7 +468,8 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
 
   // coefficient mode: the island tasks' inverse transforms only need the coefficients — they start beside
   // the convolve and the inter transforms (in residual-plane mode the residual is gathered later)
-  if ((phases & VP9HIP_PHASE_INTER) && (phases & VP9HIP_PHASE_INTRA) && P->n_islands && S->have_coeffs && !dec->have_res)
+  static const bool prepass = getenv("VP9HIP_FUSED_RESIDUAL") == nullptr;  // else the fused kernel does it
+  if (prepass && (phases & VP9HIP_PHASE_INTER) && (phases & VP9HIP_PHASE_INTRA) && P->n_islands && S->have_coeffs && !dec->have_res)
     DEC_CTX(dec, vp9hip_intra_residual_begin(dec->ctx, (const vp9hip_intra_task *)S->d_isl_tasks.p,
                                              (const vp9hip_intra_island *)S->d_islands.p, P->n_islands,
                                              (const int32_t *)S->d_wave_off.p, (const int32_t *)S->d_coeffs.p, dst));
