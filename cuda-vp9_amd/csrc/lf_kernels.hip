@@ -403,6 +403,18 @@ __device__ __forceinline__ void st_sc1(unsigned *p, unsigned v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Hand-off granule (MI355X_MICROARCH.md, persistent kernels: "handoff-1to1", data-tagged granules): one naturally
+// aligned 8-byte {sample dword, tag} written by ONE sc1 store and polled with sc1 loads; the tag is the launch's
+// generation number, so a granule of an earlier launch never passes for this one.  One memory round trip per
+// hand-off instead of three (write-through stores drained, counter, poll, sc1 loads).
+typedef unsigned long long lf_granule;
+__device__ __forceinline__ lf_granule ld_granule(const lf_granule *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_granule(lf_granule *p, unsigned data, unsigned tag) {
+  __hip_atomic_store(p, ((lf_granule)tag << 32) | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename Pix, int N>
 __device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9hip_lfm *__restrict__ lfms, int sb_cols,
                                             int sr, int pl, const LfThreshDev &th, const FrameDev &f, int mi_rows,
@@ -533,7 +545,8 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
                                              int sb_cols, int sr, int pl, const LfThreshDev &th, const FrameDev &f,
                                              int mi_rows, int *vprog_prev, int *hprog_prev, int *vprog_mine,
                                              int *hprog_mine, int *err, volatile unsigned *flags,
-                                             const int *gate_done, const int *gate_expected, int sb_rows) {
+                                             const int *gate_done, const int *gate_expected, int sb_rows,
+                                             lf_granule *hand_base, unsigned gen) {
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int PPD = 4 / sizeof(Pix);
   constexpr int n = N;
@@ -555,6 +568,11 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   const int mrows = N == 32 ? ((rows_mi + 1) >> 1) : rows_mi;
   const int ncols = min(sb_cols, (pw + n - 1) / n);  // superblocks of this plane row
   bool dead = false;
+  // this plane's hand-off granules: 8 rows per superblock row, a granule per sample dword
+  const int hpitch = stride / PPD;
+  lf_granule *hand = hand_base;
+  for (int q = 0; q < pl; ++q) hand += (size_t)sb_rows * 8 * (f.stride[q] / PPD);
+  const bool bottom_row = sr == sb_rows - 1 || y0 + n >= ph;  // nobody below: the bottom rows go to the frame
 
   unsigned reg[KI];  // wave 1: interior of the next superblock between phase B and phase C
 
@@ -618,15 +636,29 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
 #pragma unroll
     for (int k = 0; k < KA; ++k) above[k] = 0;
     if (sr > 0) {
-      wait_for(hprog_prev, sc + 1);                      // its horizontal pass of sc
-      if (sc + 1 < ncols) wait_for(vprog_prev, sc + 2);  // its vertical pass of sc+1 (last 8 columns)
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // the row above published them as tagged granules — columns 0..55 of this superblock after its horizontal
+      // pass of superblock sc, the last 8 after the first position of its vertical pass of sc+1: poll until every
+      // granule this wave needs carries this launch's tag
+      int spins = 0;
+      for (;;) {
+        bool ok = true;
 #pragma unroll
-      for (int k = 0; k < KA; ++k) {
-        const int i = lane + 64 * k;
-        const int r = i / DPR, d = i - r * DPR;
-        const int gx = x0 + d * PPD, gy = y0 - 8 + r;
-        if (i < 8 * DPR && gx < pw) above[k] = ld_sc1((const unsigned *)(plane + (size_t)gy * stride + gx));
+        for (int k = 0; k < KA; ++k) {
+          const int i = lane + 64 * k;
+          const int r = i / DPR, d = i - r * DPR;
+          const int gx = x0 + d * PPD;
+          if (i < 8 * DPR && gx < pw) {
+            const lf_granule g = ld_granule(&hand[(size_t)((sr - 1) * 8 + r) * hpitch + gx / PPD]);
+            above[k] = (unsigned)g;
+            ok = ok && (unsigned)(g >> 32) == gen;
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0 || dead) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > LF_SPIN_LIMIT) {
+          if (lane == 0) atomicExch(err, 1);
+          dead = true;
+        }
       }
     }
 #pragma unroll
@@ -674,13 +706,13 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       }
     }
     if (part == 0 && sr > 0) {
-      // tile rows 0..7 (the 8 rows above, which the horizontal pass changed), tile columns 8 .. n+7: lines
-      // shared with row sr-1, write-through (see lf_row_body); their left strip went out a step ago
+      // tile rows 0..7 (the 8 rows above, final after this row's horizontal pass), tile columns 8 .. n+7; the row
+      // above handed them over as granules and never wrote them to the frame; their left strip went out a step ago
       constexpr int ed = n / PPD;  // dwords per row
       for (int i = lane; i < 8 * ed; i += 64) {
         const int r = i / ed, d = 8 / PPD + i % ed;
         const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
-        if (gx < pw) st_sc1((unsigned *)(plane + (size_t)gy * stride + gx), t32[r * TPD + d]);
+        if (gx < pw) *(unsigned *)(plane + (size_t)gy * stride + gx) = t32[r * TPD + d];
       }
     }
   };
@@ -692,9 +724,11 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       const int r = n + i / wd, d = i % wd;
       const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
       if (d * PPD < c0 || d * PPD >= c1 || gx < 0 || gx >= pw || gy >= ph) continue;
-      st_sc1((unsigned *)(plane + (size_t)gy * stride + gx), t32[r * TPD + d]);
+      if (bottom_row)
+        *(unsigned *)(plane + (size_t)gy * stride + gx) = t32[r * TPD + d];
+      else  // for the row below only, which writes the rows' final values to the frame after its horizontal pass
+        st_granule(&hand[(size_t)(sr * 8 + (r - n)) * hpitch + gx / PPD], t32[r * TPD + d], gen);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   // wave 2 (publisher) sends the hand-off rows out and publishes the progress once they have drained —
@@ -734,7 +768,6 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       // rows of sc-1 it overwrites; then its share of the write-back of sc-1.
       if (sc > 0) {
         handoff((const unsigned *)(tiles + ((sc - 1) & 1) * TILE), x0 - n, 8, n);
-        if (lane == 0) __hip_atomic_store(hprog_mine, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       for (int spins = 0; flags[0] < (unsigned)(sc + 1); ++spins) {  // wave 0 of this workgroup: bounded all the same
         __builtin_amdgcn_s_sleep(1);
@@ -745,7 +778,6 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       if (sc > 0) handoff(t32, x0, 0, 8);
-      if (lane == 0) __hip_atomic_store(vprog_mine, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (sc > 0) bulk_writeback(sc - 1, 1);
     }
     __syncthreads();
@@ -770,7 +802,6 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   }
   if (wave == 2) {  // the last superblock's bottom rows, right strip included
     handoff((const unsigned *)(tiles + ((ncols - 1) & 1) * TILE), (ncols - 1) * n, 8, n + 8);
-    if (lane == 0) __hip_atomic_store(hprog_mine, sb_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bulk_writeback(ncols - 1, 1);
   }
   if (wave == 3) bulk_writeback(ncols - 1, 0);
@@ -779,7 +810,8 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
 template <typename Pix, int SH>
 __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                                        LfThreshDev th, FrameDev f, int mi_rows, int *progress,
-                                                       int *err, const int *gate_done, const int *gate_expected) {
+                                                       int *err, const int *gate_done, const int *gate_expected,
+                                                       lf_granule *hand, unsigned gen) {
   __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
   __shared__ unsigned ctls[2 * 256];
   __shared__ unsigned flags[2];
@@ -790,10 +822,10 @@ __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restr
   int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
   if (pl == 0 || f.awidth[pl] == f.awidth[0])
     lf_row2_body<Pix, 64, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
-                          gate_done, gate_expected, sb_rows);
+                          gate_done, gate_expected, sb_rows, hand, gen);
   else
     lf_row2_body<Pix, 32, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
-                          gate_done, gate_expected, sb_rows);
+                          gate_done, gate_expected, sb_rows, hand, gen);
 }
 
 // The island walk and the loop filter of a frame as ONE launch: workgroups [0, sb_rows * planes) are the
@@ -809,7 +841,7 @@ __global__ __launch_bounds__(256) void walk_lf_kernel(const vp9hip_lfm *__restri
                                                       const vp9hip_intra_task *__restrict__ tasks,
                                                       const vp9hip_intra_island *__restrict__ islands,
                                                       const int32_t *__restrict__ wave_off, ResidDev rd,
-                                                      const int32_t *__restrict__ coeffs) {
+                                                      const int32_t *__restrict__ coeffs, lf_granule *hand, unsigned gen) {
   const int n_lf = sb_rows * planes;
   if ((int)blockIdx.x >= n_lf) {
     const int island = (int)blockIdx.x - n_lf;
@@ -836,10 +868,10 @@ __global__ __launch_bounds__(256) void walk_lf_kernel(const vp9hip_lfm *__restri
   int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
   if (pl == 0 || f.awidth[pl] == f.awidth[0])
     lf_row2_body<Pix, 64, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
-                              gate_done, gate_expected, sb_rows);
+                              gate_done, gate_expected, sb_rows, hand, gen);
   else
     lf_row2_body<Pix, 32, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
-                              gate_done, gate_expected, sb_rows);
+                              gate_done, gate_expected, sb_rows, hand, gen);
 }
 
 template <typename Pix>
@@ -858,6 +890,29 @@ __global__ __launch_bounds__(64) void lf_rows_kernel(const vp9hip_lfm *__restric
 }
 
 }  // namespace
+
+// The hand-off granules of the row-walking filter (8 rows per superblock row and plane, 8 bytes per sample
+// dword) and the generation number that tags this launch's granules.
+static int lf_handoff_buffer(vp9hip_ctx *ctx, const vp9hip_frame *frame, int sb_rows, unsigned *gen) {
+  const int ppd = frame->hbd ? 2 : 4;
+  size_t need = 0;
+  for (int p = 0; p < 3; ++p)
+    if (frame->plane[p]) need += (size_t)sb_rows * 8 * (size_t)(frame->stride[p] / ppd) * sizeof(lf_granule);
+  if (need > ctx->lf_hand_bytes || ctx->lf_gen == 0xffffffffu) {
+    VP9HIP_CHECK(ctx, hipDeviceSynchronize());  // earlier launches may still use the old buffer / old tags
+    if (need > ctx->lf_hand_bytes) {
+      if (ctx->lf_hand) VP9HIP_CHECK(ctx, hipFree(ctx->lf_hand));
+      ctx->lf_hand = nullptr;
+      ctx->lf_hand_bytes = 0;
+      VP9HIP_CHECK(ctx, hipMalloc(&ctx->lf_hand, need + need / 4));
+      ctx->lf_hand_bytes = need + need / 4;
+    }
+    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_hand, 0, ctx->lf_hand_bytes));
+    ctx->lf_gen = 0;
+  }
+  *gen = ++ctx->lf_gen;
+  return VP9HIP_OK;
+}
 
 static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
                      const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes, const int *d_gate,
@@ -896,6 +951,11 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
     }
     int *err = ctx->lf_err_flag;
     ctx->lf_err_armed = true;
+    unsigned gen = 0;
+    {
+      int rc2 = lf_handoff_buffer(ctx, frame, sb_rows, &gen);
+      if (rc2) return rc2;
+    }
     if (mode == 2) {
 // Unused dynamic LDS on top of the kernel's own, so that at most ONE of these workgroups fits a CU (160 KB):
 // a row that waits for islands (vp9hip_intra_islands_lf) must leave the CU's registers to an island
@@ -907,7 +967,7 @@ static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, i
 #define LF_LDS_PAD(PIX) (84 * 1024 - (int)sizeof(PIX) * 2 * 72 * 76 - 4096)
 #define LF_ROWS2(PIX, SH)                                                                                       \
   hipLaunchKernelGGL((lf_rows2_kernel<PIX, SH>), dim3(sb_rows, planes), dim3(256), d_gate ? LF_LDS_PAD(PIX) : 0, st, d_lfm, sb_cols, sb_rows, \
-                     th, f, mi_rows, progress, err, d_gate, d_sb_expected)
+                     th, f, mi_rows, progress, err, d_gate, d_sb_expected, (lf_granule *)ctx->lf_hand, gen)
       if (!frame->hbd)
         LF_ROWS2(uint8_t, 0);
       else if (frame->bit_depth == 10)
@@ -1052,7 +1112,12 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
 #define WALK_LF(PIX, SH)                                                                                              \
   hipLaunchKernelGGL((walk_lf_kernel<PIX, SH>), dim3(grid), dim3(256), 0, ctx->stream, d_lfm, sb_cols, sb_rows, planes, th, f, \
                      frame->aheight[0] / 8, (int *)ctx->scratch, ctx->lf_err_flag, d_gate, d_sb_expected, d_tasks, d_islands, \
-                     d_wave_off, rd, k_coeffs)
+                     d_wave_off, rd, k_coeffs, (lf_granule *)ctx->lf_hand, gen)
+    unsigned gen = 0;
+    {
+      int rc2 = lf_handoff_buffer(ctx, frame, sb_rows, &gen);
+      if (rc2) return rc2;
+    }
     if (!frame->hbd)
       WALK_LF(uint8_t, 0);
     else if (frame->bit_depth == 10)

@@ -43,6 +43,7 @@ extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->lf_err_flag) (void)hipFree(ctx->lf_err_flag);
+  if (ctx->lf_hand) (void)hipFree(ctx->lf_hand);
   if (ctx->resid) (void)hipFree(ctx->resid);
   if (ctx->ev_resid_start) {
     (void)hipEventDestroy(ctx->ev_resid_start);

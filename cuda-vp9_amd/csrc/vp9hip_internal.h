@@ -19,6 +19,9 @@ struct vp9hip_ctx {
   int cu_count;
   int *lf_err_flag;  // device flag (own allocation): a loop-filter wait timed out; set until vp9hip_sync reports it
   bool lf_err_armed; // a loop filter was launched since the flag was last read
+  void *lf_hand;     // hand-off granules of the row-walking loop filter (lf_kernels.hip)
+  size_t lf_hand_bytes;
+  unsigned lf_gen;   // generation number of the last launch
   void *d_taps;  // packed i8 convolve taps (inter fast path)
   hipEvent_t *ev_begin, *ev_end;  // VP9HIP_TIMER_SLOTS each, created lazily
   // overlap of the intra island walk with the loop filter (vp9hip_intra_islands_lf)
