@@ -34,6 +34,21 @@ def run(verbose=False):
               f"md5 {md5} == oracle")
     job.free()
     ctx.close()
+    # and one small real bitstream through the reference's vpxdec linked against the shim (when the built
+    # decoder travelled with the tree): every frame's MD5 against the CPU path's list
+    import re
+    import subprocess
+    dec = os.path.join(ROOT, "shim", "build", "vpxdec_hip_mt")
+    ivf = os.path.join(ROOT, "tests", "golden", "streams", "s704_8.ivf")
+    if os.path.exists(dec):
+        out = subprocess.run([dec, "--rawvideo", "--md5", "-o", "img-%wx%h-%4.i420", ivf], stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, timeout=300)
+        got_md5 = [l for l in out.stdout.decode(errors="replace").splitlines() if re.match(r"^[0-9a-f]{32}  img-", l)]
+        want = [l.rstrip("\n") for l in open(ivf[:-4] + ".md5") if l.strip()]
+        if out.returncode or got_md5 != want:
+            raise AssertionError("smoke: vpxdec_hip_mt on s704_8.ivf: per-frame MD5s differ from the CPU path's")
+        if verbose:
+            print(f"smoke ok: s704_8.ivf through vpxdec -> decode_tiles -> wrap_cuda_* -> HIP, {len(want)} frames MD5-equal")
 
 
 if __name__ == "__main__":
