@@ -235,7 +235,9 @@ int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_ro
                              const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame,
                              int planes /* 1: Y only, 3: Y,U,V */);
 
-/* The island walk and the loop filter of the same frame side by side (HIP streams inside the context):
+/* The island walk and the loop filter of the same frame side by side — one launch (walk_lf_kernel: the
+ * filter's rows are the first workgroups, the islands the rest; VP9HIP_LF_TWO_STREAMS=1 selects the earlier form,
+ * two launches on two HIP streams of the context):
  * the filter takes superblock (r, c) once the islands touching superblocks (r..r+1, c-1..c+1) are done
  * (an unfinished island there would still read samples the filter changes), not when the whole walk
  * is.  The hand-over is per (island, superblock): bit 0 of vp9hip_intra_task.reserved marks the LAST
@@ -244,7 +246,9 @@ int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_ro
  * islands[i].reserved = the superblock bounding box of an island is informational).  Frames with
  * very large components (key frames: the vp9hip_intra_pred_waves remainder) use the two calls in
  * sequence instead.  Ordered after everything enqueued before on the context, and later work is
- * ordered after both kernels.  At most 255 x 255 superblocks. */
+ * ordered after both.  At most 255 superblocks in either direction and 16384 in all (128 x 128: 8192 x 8192
+ * samples); larger frames are refused here — the frame driver (vp9hip_decoder_run) then runs the two phases in
+ * sequence. */
 int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks, const vp9hip_intra_island *d_islands,
                             int n_islands, const int32_t *d_wave_off, const int32_t *d_coeffs,
                             const int32_t *d_sb_expected, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
