@@ -68,7 +68,7 @@ class FrameParams(ctypes.Structure):
 
 
 class CoeffLayout(ctypes.Structure):
-    _fields_ = [("eob", ctypes.c_void_p * 3), ("eob_stride", ctypes.c_int32 * 3), ("reserved", ctypes.c_int32),
+    _fields_ = [("eob", ctypes.c_void_p * 3), ("eob_stride", ctypes.c_int32 * 3), ("eob_shift", ctypes.c_int32),
                 ("block_off", ctypes.c_void_p), ("plane_base", ctypes.c_int64 * 3), ("total", ctypes.c_int64),
                 ("regions", ctypes.c_void_p), ("n_regions", ctypes.c_int64)]
 

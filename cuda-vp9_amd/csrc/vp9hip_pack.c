@@ -742,7 +742,7 @@ static void pk_pass1(void *argp, int tid) {
             brun[p] += nn;
             run[p] += nn;
             if (coeffs && coeffs->eob[p])
-              eob = coeffs->eob[p][(size_t)y * coeffs->eob_stride[p] + x];
+              eob = coeffs->eob[p][(size_t)(y >> coeffs->eob_shift) * coeffs->eob_stride[p] + (x >> coeffs->eob_shift)];
             else if (P->assume_coded)
               eob = 1;
             if (eob < 0 || eob > nn) JOB_FAIL(j, tid, "vp9hip_pack_frame: bad eob %d (block %d plane %d)", eob, i, p);

@@ -25,6 +25,12 @@ struct VP9Decoder;
 struct VP9Common;
 struct frame_buffer; /* frameBuf, vpx-master/buffers_struct.h:9-15 */
 
+/* The eob plane's granularity: 0 (default) = the reference's layout, one int per SAMPLE position
+ * (eob_buf[4 * row * stride + 4 * col], vp9_decodeframe.c:969, 1018); 2 = one int per 4x4 position
+ * (plane_eob[plane][(y >> 2) * (stride >> 2) + (x >> 2)]: 16 times denser, what patch E11 makes detoken_block
+ * write).  Call before the wrappers of the first frame. */
+void vp9hip_shim_set_eob_layout(struct VP9Decoder *pbi, int log2_granularity);
+
 /* Memory for what initBuf() (vp9_decodeframe.c:2242-2270) mallocs and frees for every frame: which = 0..2
  * the coefficient array of that plane (frameBuf.dqcoeff[plane]), 3 the eob plane (frameBuf.eob).  Page-
  * locked, owned by the shim, kept (and grown) from frame to frame; valid until the next call with the

@@ -91,7 +91,10 @@ typedef struct vp9hip_coeff_region {
 typedef struct vp9hip_coeff_layout {
   const int32_t *eob[3];
   int32_t eob_stride[3];
-  int32_t reserved;
+  /* 0: eob[plane][y * eob_stride + x] (the reference's frame-strided plane, one int per SAMPLE position);
+   * 2: eob[plane][(y >> 2) * eob_stride + (x >> 2)] — one int per 4x4 position, 16 times denser (what the
+   * patched detoken_block writes, oracle/patch_decodeframe.py E11) */
+  int32_t eob_shift;
   /* Optional (NULL = the sequential layout above).  block_off[3 * i + p]: where block i's coefficient slots of
    * plane p start inside plane p's host array, in coefficients — for callers whose entropy stage fills one
    * region per TILE COLUMN from several threads, so that slots are consecutive per tile, not

@@ -32,6 +32,9 @@ Edits (decode_tiles = vp9_decodeframe.c:2303-2639):
       with VP9HIP_SHIM_TRACE=1 (no effect otherwise)
   E10 (--mt) tile-parallel entropy stage: one thread per tile column with private list segments /
       coefficient regions / counts / error trap, merged into the canonical lists afterwards (f2)
+  E11 detoken_block (:951, :969, :1000, :1018): the eob of a transform block goes to a plane with one int per 4x4
+      position (16 times denser than one int per sample position: the packer's reads stay in cache);
+      vp9hip_shim_set_eob_layout(pbi, 2) tells the other side
   E6  `int n = cm->width * cm->height;` (:2314) sizes dqcoeff[plane] (initBuf :2266) and the block
       lists; coefficient slots cover whole transform blocks, so a frame whose size is not a multiple
       of 8 (or whose last 32x32 transform block overhangs the frame) overruns it (heap corruption,
@@ -324,6 +327,20 @@ def main():
     t = t[:i] + "  vp9hip_shim_mark(pbi, 2);\n" + t[i:]
     t = replace_once(t, "  // Get last tile data.\n", "  vp9hip_shim_mark(pbi, 3);\n  // Get last tile data.\n", "E9 mark 3")
     t = replace_once(t, "  ++fr;\n", "  vp9hip_shim_mark(pbi, 4);\n  ++fr;\n", "E9 mark 4")
+
+    # E11: one eob per 4x4 position instead of one per sample position
+    old_base = "      int *eob_buf = frameBuffer->plane_eob[plane] + by * stride + bx;\n"
+    old_store = "eob_buf[4 * row * stride + 4 * col] = eob;"
+    a = t.find("static void detoken_block(")
+    b = t.find("static void intra_decode(", a)
+    body = t[a:b]
+    if a < 0 or b < 0 or body.count(old_base) != 2 or body.count(old_store) != 2:
+        sys.exit("patch_decodeframe: anchor not found: E11 detoken_block")
+    body = body.replace(old_base, "      int *eob_buf = frameBuffer->plane_eob[plane] + (by >> 2) * (stride >> 2) + (bx >> 2);\n")
+    body = body.replace(old_store, "eob_buf[row * (stride >> 2) + col] = eob;")
+    t = t[:a] + body + t[b:]
+    t = replace_once(t, "  vp9hip_shim_attach_frame_buffer(pbi, frameBuffer);\n",
+                     "  vp9hip_shim_attach_frame_buffer(pbi, frameBuffer);\n  vp9hip_shim_set_eob_layout(pbi, 2);\n", "E11 layout call")
 
     # E5
     t = replace_once(t, "    X_Fuel(pbi);\n",

@@ -67,6 +67,7 @@
 typedef struct {
   VP9Decoder *pbi;
   const frameBuf *attached;
+  int eob_shift;
   tran_low_t *dq_start[3];
   int filter_here;
   /* bordered copies of finished frames, one per frame-buffer index */
@@ -141,6 +142,10 @@ void *vp9hip_shim_frame_memory(struct VP9Common *cm, int which, size_t bytes) {
 void vp9hip_shim_run_parallel(struct VP9Decoder *pbi, int n, void (*fn)(void *arg, int index), void *arg) {
   (void)pbi;
   for (int i = 0; i < n; ++i) fn(arg, i);
+}
+
+void vp9hip_shim_set_eob_layout(struct VP9Decoder *pbi, int log2_granularity) {
+  state_of(pbi)->eob_shift = log2_granularity == 2 ? 2 : 0;
 }
 
 void vp9hip_shim_mark(struct VP9Decoder *pbi, int mark) {
@@ -286,7 +291,8 @@ static void inverse_add(MACROBLOCKD *xd, const txb_pos *t, TX_TYPE tx_type, cons
 static int eob_at(const oracle_state *s, const MACROBLOCKD *xd, const txb_pos *t, int mi_row, int mi_col) {
   const struct macroblockd_plane *pd = &xd->plane[t->plane];
   const int by = (mi_row * MI_SIZE) >> pd->subsampling_y, bx = (mi_col * MI_SIZE) >> pd->subsampling_x;
-  return s->attached->plane_eob[t->plane][(size_t)(by + 4 * t->row) * t->stride + bx + 4 * t->col];
+  const int sh = s->eob_shift;
+  return s->attached->plane_eob[t->plane][(size_t)((by + 4 * t->row) >> sh) * (t->stride >> sh) + ((bx + 4 * t->col) >> sh)];
 }
 
 typedef void (*block_fn)(oracle_state *s, VP9_COMMON *cm, MACROBLOCKD *xd, MODE_INFO *mi, int index, int mi_row, int mi_col,

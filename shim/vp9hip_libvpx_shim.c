@@ -56,6 +56,7 @@ typedef struct {
   VP9Decoder *pbi;
   vp9hip_decoder *dec;
   const frameBuf *attached;     /* coefficient mode when non-NULL */
+  int eob_shift;                /* 0: the reference's frame-strided eob plane; 2: one int per 4x4 position (E11) */
   const tran_low_t *dq_start[3]; /* start of the per-plane coefficient arrays (attach time) */
   vp9hip_block *blocks;
   int blocks_cap;
@@ -95,6 +96,7 @@ static struct {
   int on, frames;
   double gather, pack_upload, refs, inter_wait, masks, intra_wait, download;
   double gpu_inter_ms, gpu_intra_ms;
+  double coeff_mb, blocks;
 } g_trace;
 
 static double g_mark_t[5], g_mark_sum[5], g_mark_outside;
@@ -128,6 +130,7 @@ static void trace_report(void) {
           g_trace.gpu_inter_ms / n, g_trace.masks * ms, g_trace.intra_wait * ms, g_trace.gpu_intra_ms / n, g_trace.download * ms,
           (g_trace.gather + g_trace.pack_upload + g_trace.refs + g_trace.inter_wait + g_trace.masks + g_trace.intra_wait +
            g_trace.download) * ms);
+  fprintf(stderr, "vp9hip shim: per frame: %.0f blocks, %.2f MB of coefficient slots uploaded\n", g_trace.blocks / n, g_trace.coeff_mb / n);
 }
 
 static double now_s(void) {
@@ -181,6 +184,11 @@ void vp9hip_shim_attach_frame_buffer(struct VP9Decoder *pbi, const struct frame_
   s->tile_layout_blocks = -1; /* a new frame: any tile layout belongs to the previous one */
   if (frameBuffer)
     for (int p = 0; p < 3; ++p) s->dq_start[p] = frameBuffer->dqcoeff[p];
+}
+
+void vp9hip_shim_set_eob_layout(struct VP9Decoder *pbi, int log2_granularity) {
+  shim_state *s = state_of(pbi, &pbi->common);
+  if (s) s->eob_shift = log2_granularity == 2 ? 2 : 0;
 }
 
 void *vp9hip_shim_frame_memory(struct VP9Common *cm, int which, size_t bytes) {
@@ -478,7 +486,7 @@ static int begin_frame(shim_state *s, VP9_COMMON *cm, VP9Decoder *pbi, int *size
     const int32_t *dq[3];
     for (int p = 0; p < 3; ++p) {
       L.eob[p] = s->attached->plane_eob[p];
-      L.eob_stride[p] = p ? cur->uv_stride : cur->y_stride;
+      L.eob_stride[p] = (p ? cur->uv_stride : cur->y_stride) >> s->eob_shift;
       dq[p] = (const int32_t *)s->dq_start[p];
     }
     if (sizeof(tran_low_t) != sizeof(int32_t)) {
@@ -487,7 +495,8 @@ static int begin_frame(shim_state *s, VP9_COMMON *cm, VP9Decoder *pbi, int *size
     }
     /* coefficient arrays the caller got from vp9hip_shim_frame_memory are page-locked and stay untouched
      * until the frame has been delivered: they travel asynchronously */
-    memset(&L.reserved, 0, sizeof(L) - offsetof(vp9hip_coeff_layout, reserved));
+    memset(&L.eob_shift, 0, sizeof(L) - offsetof(vp9hip_coeff_layout, eob_shift));
+    L.eob_shift = s->eob_shift;
     if (s->tile_layout_blocks >= 0) {
       /* the entropy stage ran one thread per tile column: slots are consecutive per tile (E10) */
       if (s->tile_layout_blocks != n) {
@@ -510,6 +519,14 @@ static int begin_frame(shim_state *s, VP9_COMMON *cm, VP9Decoder *pbi, int *size
     const int persistent = s->frame_mem[0] && dq[0] == (const int32_t *)s->frame_mem[0] && dq[1] == (const int32_t *)s->frame_mem[1] &&
                            dq[2] == (const int32_t *)s->frame_mem[2];
     SHIM_CHECK(s, cm, vp9hip_decoder_begin_frame_ex(s->dec, &P, s->blocks, n, &L, dq, persistent ? VP9HIP_BEGIN_HOST_PERSISTENT : 0));
+    if (g_trace.on) {
+      const vp9hip_packed *pk = vp9hip_decoder_packed(s->dec);
+      g_trace.blocks += n;
+      if (L.block_off)
+        for (int64_t r = 0; r < L.n_regions; ++r) g_trace.coeff_mb += 4e-6 * (double)L.regions[r].count;
+      else
+        g_trace.coeff_mb += 4e-6 * (double)(pk->coeff_count[0] + pk->coeff_count[1] + pk->coeff_count[2]);
+    }
   } else {
     const int64_t *res[3];
     int32_t rs[3];
