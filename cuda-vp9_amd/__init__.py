@@ -70,7 +70,31 @@ class FrameParams(ctypes.Structure):
 class CoeffLayout(ctypes.Structure):
     _fields_ = [("eob", ctypes.c_void_p * 3), ("eob_stride", ctypes.c_int32 * 3), ("eob_shift", ctypes.c_int32),
                 ("block_off", ctypes.c_void_p), ("plane_base", ctypes.c_int64 * 3), ("total", ctypes.c_int64),
-                ("regions", ctypes.c_void_p), ("n_regions", ctypes.c_int64)]
+                ("regions", ctypes.c_void_p), ("n_regions", ctypes.c_int64),
+                ("compact", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class CoeffRegion(ctypes.Structure):
+    _fields_ = [("plane", ctypes.c_int32), ("reserved", ctypes.c_int32), ("start", ctypes.c_int64), ("count", ctypes.c_int64)]
+
+
+def _apply_tile_layout(cl, tile_layout, keep):
+    """tile_layout: dict(block_off=uint32[n_blocks, 3], plane_base=[3], total=int, regions=[(plane, start, count)],
+    compact=bool) — vp9hip_coeff_layout's optional part (slots placed by the caller, include/vp9hip_pack.h)."""
+    bo = np.ascontiguousarray(tile_layout["block_off"], np.uint32)
+    keep.append(bo)
+    cl.block_off = bo.ctypes.data
+    for p in range(3):
+        cl.plane_base[p] = int(tile_layout["plane_base"][p])
+    cl.total = int(tile_layout["total"])
+    regs = tile_layout.get("regions") or []
+    arr = (CoeffRegion * max(1, len(regs)))()
+    for i, (pl, st, cnt) in enumerate(regs):
+        arr[i].plane, arr[i].start, arr[i].count = int(pl), int(st), int(cnt)
+    keep.append(arr)
+    cl.regions = ctypes.addressof(arr)
+    cl.n_regions = len(regs)
+    cl.compact = int(bool(tile_layout.get("compact")))
 
 
 class Packed(ctypes.Structure):
@@ -217,7 +241,7 @@ class Decoder:
         self._pinned.append(p)
         return np.frombuffer((ctypes.c_char * nbytes).from_address(p), dtype=dtype, count=int(n))
 
-    def begin_frame(self, params, blocks, eob_planes=None, coef_planes=None, persistent=False):
+    def begin_frame(self, params, blocks, eob_planes=None, coef_planes=None, persistent=False, tile_layout=None):
         """persistent: coef_planes are page-locked arrays (host_array) left alone until the frame was run
         and synchronised: nothing is copied synchronously (VP9HIP_BEGIN_HOST_PERSISTENT).  Returns the
         ring set the frame went to."""
@@ -230,6 +254,8 @@ class Decoder:
                 a = np.ascontiguousarray(eob_planes[p], np.int32)
                 self._keep.append(a)
                 cl.eob[p], cl.eob_stride[p] = a.ctypes.data, a.shape[1]
+            if tile_layout is not None:
+                _apply_tile_layout(cl, tile_layout, self._keep)
         if coef_planes is not None:
             arrs = [np.ascontiguousarray(c, np.int32) for c in coef_planes]
             self._keep += arrs
@@ -280,7 +306,7 @@ class Packer:
         """vp9hip_pack_frame without copying the lists out (host packing time measurements)."""
         return self.pack(params, blocks, eob_planes, copy=False)
 
-    def pack(self, params: FrameParams, blocks, eob_planes=None, copy=True):
+    def pack(self, params: FrameParams, blocks, eob_planes=None, copy=True, tile_layout=None):
         """blocks: BLOCK_DTYPE array in decode order; eob_planes: three int32 2-D arrays indexed [y, x]
         (the reference's plane_eob layout) or None.  Returns a dict of numpy copies of the lists."""
         blocks = np.ascontiguousarray(blocks, BLOCK_DTYPE)
@@ -293,6 +319,8 @@ class Packer:
                 keep.append(a)
                 cl.eob[p] = a.ctypes.data
                 cl.eob_stride[p] = a.shape[1]
+            if tile_layout is not None:
+                _apply_tile_layout(cl, tile_layout, keep)
         out = Packed()
         rc = lib().vp9hip_pack_frame(self.handle, ctypes.byref(params), blocks.ctypes.data, len(blocks),
                                      ctypes.byref(cl) if cl is not None else None, ctypes.byref(out))

@@ -355,8 +355,10 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
       }
       if (dc_kind)
         dc_coeff = src[0];  // only the DC term is defined (and read) at eob <= 1
-      else if (t < bs)
-        for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = src[i * bs + t];
+      else if (t < bs) {
+        const int rd = identity ? bs : txfm::coeff_rows(tk.eob, lossless ? 0 : (tk.tx_type & 3), bs);
+        for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = i < rd ? src[i * bs + t] : 0;
+      }
     }
   }
   slot_sync();
@@ -423,8 +425,10 @@ __device__ __forceinline__ void residual_chunk(int (*tiles)[32 * TPITCH], const 
     }
     if (dc_kind)
       dc_coeff = src[0];
-    else if (t < bs)
-      for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = src[i * bs + t];
+    else if (t < bs) {
+      const int rd = identity ? bs : txfm::coeff_rows(tk.eob, lossless ? 0 : (tk.tx_type & 3), bs);
+      for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = i < rd ? src[i * bs + t] : 0;
+    }
   }
   slot_sync();
   if (coded && !dc_kind && !identity && t < bs) {

@@ -18,6 +18,15 @@
 
 namespace txfm {
 
+// Rows of an N x N coefficient block that can be non-zero (the reference's clearing rule, vp9_decodeframe.c:960-967):
+// the only rows the kernels read — and the only ones a compact slot holds.  Same as vp9hip_coeff_rows (vp9hip_pack.h).
+__device__ __forceinline__ int coeff_rows(int eob, int tx_type, int n) {
+  if (eob == 1) return 1;
+  if (tx_type == 0 && n <= 16 && eob <= 10) return 4;
+  if (n == 32 && eob <= 34) return 8;
+  return n;
+}
+
 // round(16384 * cos(k*pi/64)), vpx_dsp/txfm_common.h:28-58
 #define CK(k) (txfm::kCos[k])
 __device__ constexpr int kCos[33] = { 16384, 16364, 16305, 16207, 16069, 15893, 15679, 15426, 15137,

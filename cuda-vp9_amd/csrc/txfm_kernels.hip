@@ -42,8 +42,9 @@ __device__ __forceinline__ void idct_add_body(int *lds, int wg, const vp9hip_txb
 
   int v[N];
   if (active && !dc_path && !wht_dc) {
+    const int rd = txfm::coeff_rows(eob, lossless ? 0 : tx_type, N);  // rows past rd are zero and, in a compact slot, absent
 #pragma unroll
-    for (int i = 0; i < N; ++i) tile[i * PITCH + t] = src[i * N + t];
+    for (int i = 0; i < N; ++i) tile[i * PITCH + t] = i < rd ? src[i * N + t] : 0;
   }
   __syncthreads();
   if (active && !dc_path && !wht_dc) {

@@ -535,7 +535,7 @@ typedef struct pk_job_s {
   /* offsets handed to pass 1 */
   int32_t inter_off[PK_MAX_THREADS], txb_off[PK_MAX_THREADS], intra_off[PK_MAX_THREADS];
   int64_t run_off[PK_MAX_THREADS][3];
-  int64_t coeff_base[3];
+  int64_t coeff_base[3], coeff_total;
   /* per-range results of pass 1 */
   int32_t n_txb[PK_MAX_THREADS], hist_inter[PK_MAX_THREADS][6], hist_txb[PK_MAX_THREADS][4];
   uint32_t refs_used[PK_MAX_THREADS];
@@ -560,6 +560,19 @@ typedef struct pk_job_s {
     snprintf((j)->errmsg[tid], sizeof((j)->errmsg[tid]), __VA_ARGS__); \
     return;                                                          \
   } while (0)
+
+/* vp9hip_pack.h: rows / coefficients of a transform block's slot that can be non-zero */
+int vp9hip_coeff_rows(int eob, int tx_type, int tx_size) {
+  const int n = 4 << tx_size;
+  if (eob <= 0) return 0;
+  if (eob == 1) return 1;
+  if (tx_type == 0 && tx_size <= 2 && eob <= 10) return 4;
+  if (tx_size == 3 && eob <= 34) return 8;
+  return n;
+}
+int vp9hip_coeff_extent(int eob, int tx_type, int tx_size) {
+  return vp9hip_coeff_rows(eob, tx_type, tx_size) * (4 << tx_size);
+}
 
 /* pass 0: validate, count (exact but for the residual records, whose number depends on the eobs: upper bound) */
 static void pk_pass0(void *argp, int tid) {
@@ -723,6 +736,7 @@ static void pk_pass1(void *argp, int tid) {
     /* transform blocks: vp9_foreach_transformed_block_in_plane order, clipped to the frame */
     int eobtotal = 0;
     const uint32_t *boff = (coeffs && coeffs->block_off) ? &coeffs->block_off[3 * (size_t)i] : NULL;
+    const int compact = boff && coeffs->compact;
     int64_t brun[3] = { 0, 0, 0 };
     for (int p = 0; p < 3; ++p) {
       const int s = p ? ss : 0;
@@ -737,16 +751,27 @@ static void pk_pass1(void *argp, int tid) {
           int eob = 0;
           uint32_t off = 0;
           if (!b->skip) {
-            off = (uint32_t)(j->coeff_base[p] + run[p]);
-            if (boff) off = (uint32_t)(j->coeff_base[p] + boff[p] + brun[p]);
-            brun[p] += nn;
-            run[p] += nn;
             if (coeffs && coeffs->eob[p])
               eob = coeffs->eob[p][(size_t)(y >> coeffs->eob_shift) * coeffs->eob_stride[p] + (x >> coeffs->eob_shift)];
             else if (P->assume_coded)
               eob = 1;
             if (eob < 0 || eob > nn) JOB_FAIL(j, tid, "vp9hip_pack_frame: bad eob %d (block %d plane %d)", eob, i, p);
             eobtotal += eob;
+            off = (uint32_t)(j->coeff_base[p] + run[p]);
+            if (boff) off = (uint32_t)(j->coeff_base[p] + boff[p] + brun[p]);
+            int ext = nn;
+            if (compact) { /* the slot holds the rows the clearing rule leaves (vp9hip_coeff_extent), nothing at eob 0 */
+              int txt = 0;
+              if (!inter && !P->lossless && p == 0 && tx < 3) {
+                const int m = sub8 ? b->sub_mode[(row << 1) + col] : b->mode;
+                txt = m <= 9 ? kModeToTxType[m] : 0;
+              }
+              ext = vp9hip_coeff_extent(eob, txt, tx);
+            }
+            if (eob > 0 && (int64_t)off + ext > j->coeff_total)
+              JOB_FAIL(j, tid, "vp9hip_pack_frame: coefficient slot of block %d plane %d ends past the buffer", i, p);
+            brun[p] += ext;
+            run[p] += nn;
           }
           if (inter) {
             if (eob > 0) {
@@ -926,6 +951,9 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
   }
   if (out->coeff_total > (int64_t)UINT32_MAX) PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: too many coefficients");
   memcpy(j->coeff_base, out->coeff_base, sizeof(j->coeff_base));
+  j->coeff_total = out->coeff_total;
+  if (coeffs && coeffs->compact && !coeffs->block_off)
+    PK_FAIL(pk, VP9HIP_EINVAL, "vp9hip_pack_frame: the compact coefficient layout needs block_off");
 
   const size_t n_sb = (size_t)sb_rows * sb_cols;
   if (vec_reserve(&pk->inter, (n_inter + 1) * sizeof(vp9hip_inter_task)) ||

@@ -61,11 +61,17 @@ void vp9hip_shim_set_gpu_loop_filter(struct VP9Decoder *pbi, int enable);
  *     canonical (decode-order) list, the offset of its coefficient slots inside each plane's array.
  *   vp9hip_shim_set_tile_layout: the stretches of the coefficient arrays the threads filled — region t, plane p:
  *     [start[3 * t + p], start[3 * t + p] + count[3 * t + p]) coefficients.  Valid for the frame being decoded;
- *     the next wrap_cuda_* call consumes it. */
+ *     the next wrap_cuda_* call consumes it.  flags: VP9HIP_SHIM_COEFF_COMPACT — every transform block's slot
+ *     holds only vp9hip_coeff_extent(eob, tx_type, tx_size) coefficients (vp9hip_pack.h; the rows the reference's
+ *     own clearing rule leaves non-zero, nothing at eob 0), slots without gaps (E12): the entropy threads copy a
+ *     fraction of the bytes and so does the upload. */
+#define VP9HIP_SHIM_COEFF_COMPACT 1
 void vp9hip_shim_run_parallel(struct VP9Decoder *pbi, int n, void (*fn)(void *arg, int index), void *arg);
 #include <stdint.h>
+#include "vp9hip_pack.h" /* vp9hip_coeff_extent */
 uint32_t *vp9hip_shim_block_off_buffer(struct VP9Decoder *pbi, int n_blocks);
-void vp9hip_shim_set_tile_layout(struct VP9Decoder *pbi, int n_blocks, int n_regions, const int64_t *start, const int64_t *count);
+void vp9hip_shim_set_tile_layout(struct VP9Decoder *pbi, int n_blocks, int n_regions, const int64_t *start, const int64_t *count,
+                                 int flags);
 
 /* Measurement aid (VP9HIP_SHIM_TRACE=1; a no-op otherwise): marks 0..4 placed in decode_tiles — entry, before
  * the entropy loop, after it, after the two entry points, before return — split a frame's host time into

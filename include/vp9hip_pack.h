@@ -107,7 +107,21 @@ typedef struct vp9hip_coeff_layout {
    * driver copies to the device, each to plane_base[plane] + start) */
   const vp9hip_coeff_region *regions;
   int64_t n_regions;
+  /* != 0 (needs block_off): a transform block's slot holds only vp9hip_coeff_extent() coefficients — the rows
+   * the reference's own clearing rule says can be non-zero (detoken_block, vp9_decodeframe.c:960-967) — and
+   * nothing at eob 0; slots follow each other without gaps (oracle/patch_decodeframe.py E12).  0: every slot
+   * has the full N*N coefficients, as the reference writes them. */
+  int32_t compact, reserved;
 } vp9hip_coeff_layout;
+
+/* Rows of an N x N coefficient block (N = 4 << tx_size, row-major) that can hold non-zero values, by the rule
+ * with which the reference clears its scratch block after use (vp9_decodeframe.c:960-967 and :1009-1016, the
+ * same as libvpx's inverse_transform_block_*): eob 1 -> only [0]; DCT_DCT up to 16x16 with eob <= 10 -> the
+ * first 4 rows; 32x32 with eob <= 34 -> the first 256 coefficients = 8 rows; otherwise all.  The kernels read
+ * exactly these rows (the rest is zero by that rule), the compact layout stores exactly these rows.
+ * tx_type: 0 = DCT_DCT.  Kept in step with txfm::coeff_rows() in csrc/txfm_device.h. */
+int vp9hip_coeff_rows(int eob, int tx_type, int tx_size);
+int vp9hip_coeff_extent(int eob, int tx_type, int tx_size);
 
 typedef struct vp9hip_packed {
   /* inter prediction, sorted into the six classes of vp9hip_inter_pred_batch */

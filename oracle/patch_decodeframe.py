@@ -35,6 +35,11 @@ Edits (decode_tiles = vp9_decodeframe.c:2303-2639):
   E11 detoken_block (:951, :969, :1000, :1018): the eob of a transform block goes to a plane with one int per 4x4
       position (16 times denser than one int per sample position: the packer's reads stay in cache);
       vp9hip_shim_set_eob_layout(pbi, 2) tells the other side
+  E12 (--mt) detoken_block (:958, :971, :1006, :1020): a transform block's slot takes only the rows the clearing
+      rule a few lines further down leaves non-zero (vp9hip_coeff_extent, include/vp9hip_pack.h) and nothing at
+      eob 0; the slots of a tile column follow each other without gaps.  The threads copy, and the frame driver
+      uploads, a fraction of the bytes (S-2160: 49.6 -> 26.8 MB per frame, S-1440: 3.8 -> 1.7).  vp9hip_shim_set_tile_layout(...,
+      VP9HIP_SHIM_COEFF_COMPACT) tells the other side; the serial loop (row_mt, inverse tile order) keeps full slots.
   E6  `int n = cm->width * cm->height;` (:2314) sizes dqcoeff[plane] (initBuf :2266) and the block
       lists; coefficient slots cover whole transform blocks, so a frame whose size is not a multiple
       of 8 (or whose last 32x32 transform block overhangs the frame) overruns it (heap corruption,
@@ -211,7 +216,7 @@ static void vp9hip_parse_frame_mt(VP9Decoder *pbi, int tile_rows, int tile_cols,
         start[t][p] = job->seg[t].coef_start[p];
         used[t][p] = job->seg[t].coef_used[p];
       }
-    vp9hip_shim_set_tile_layout(pbi, total, tile_cols, &start[0][0], &used[0][0]);
+    vp9hip_shim_set_tile_layout(pbi, total, tile_cols, &start[0][0], &used[0][0], VP9HIP_SHIM_COEFF_COMPACT);
     if (!cm->frame_parallel_decoding_mode)
       for (t = 0; t < tile_cols * tile_rows; ++t) vp9_accumulate_frame_counts(&cm->counts, &pbi->tile_worker_data[t].counts, 1);
   }
@@ -225,9 +230,10 @@ static void vp9hip_parse_frame_mt(VP9Decoder *pbi, int tile_rows, int tile_cols,
 
 
 def patch_mt(t):
-    """E10: tile-parallel entropy stage (the serial loop stays for frames with one tile column)."""
+    """E10: tile-parallel entropy stage (the serial loop stays for row_mt / inverse tile order); E12: compact slots."""
     t = replace_once(t, "#define MAX_VP9_HEADER_SIZE 80\n",
                      "#define MAX_VP9_HEADER_SIZE 80\n"
+                     "#include \"vp9hip_pack.h\" /* E12: vp9hip_coeff_extent */\n"
                      "/* E10: where the running tile-column thread records each block's coefficient slot offsets */\n"
                      "static __thread uint32_t (*vp9hip_tl_coef_off)[3];\n"
                      "static __thread tran_low_t *vp9hip_tl_coef_base[3];\n"
@@ -242,6 +248,19 @@ def patch_mt(t):
     t = replace_once(t, "static const uint8_t *decode_tiles(VP9Decoder *pbi, const uint8_t *data, const uint8_t *data_end) {",
                      MT_CODE + "\nstatic const uint8_t *decode_tiles(VP9Decoder *pbi, const uint8_t *data, const uint8_t *data_end) {",
                      "E10 helper insertion")
+    # E12: compact coefficient slots while a tile-column thread is parsing
+    a = t.find("static void detoken_block(")
+    b = t.find("static void intra_decode(", a)
+    body = t[a:b]
+    old_copy = "          memcpy(frameBuffer->dqcoeff[plane], dq, n * sizeof(tran_low_t));\n"
+    old_step = "          frameBuffer->dqcoeff[plane] += n;\n"
+    if a < 0 or b < 0 or body.count(old_copy) != 2 or body.count(old_step) != 2 or body.count("const TX_TYPE tx_type") != 1:
+        sys.exit("patch_decodeframe: anchor not found: E12 detoken_block")
+    for txt in ("tx_type", "DCT_DCT"):  # the intra branch has the block's tx_type, the inter branch is DCT_DCT
+        body = body.replace(old_copy, "          const int ext_ = vp9hip_tl_coef_off ? vp9hip_coeff_extent(eob, %s, tx_size) : n;\n"
+                            "          memcpy(frameBuffer->dqcoeff[plane], dq, ext_ * sizeof(tran_low_t));\n" % txt, 1)
+    body = body.replace(old_step, "          frameBuffer->dqcoeff[plane] += ext_;\n")
+    t = t[:a] + body + t[b:]
     a = t.find("  //entropy decoder\n")
     b = t.find("  //go to start\n", a)
     if a < 0 or b < 0:
@@ -253,7 +272,7 @@ def patch_mt(t):
     if loop.rstrip().endswith("vp9hip_shim_mark(pbi, 2);"):
         loop = loop[:loop.rstrip().rfind("vp9hip_shim_mark(pbi, 2);")]
         marks = "  vp9hip_shim_mark(pbi, 2);\n"
-    t = (t[:a] + "  //entropy decoder\n  if (tile_cols > 1 && pbi->row_mt != 1 && !pbi->inv_tile_order) {\n"
+    t = (t[:a] + "  //entropy decoder\n  if (pbi->row_mt != 1 && !pbi->inv_tile_order) {\n"
          "    vp9hip_parse_frame_mt(pbi, tile_rows, tile_cols, frameBuffer, &MiBuf, size_for_mb, subsize_array, n);\n"
          "  } else {\n" + loop + "  }\n" + marks + t[b:])
     return t

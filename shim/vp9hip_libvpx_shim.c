@@ -71,7 +71,7 @@ typedef struct {
   size_t frame_mem_req[4]; /* bytes the caller asked for last */
   /* tile-parallel entropy stage: per-block coefficient offsets + the filled regions of this frame */
   uint32_t *block_off;
-  int block_off_cap, tile_layout_blocks;
+  int block_off_cap, tile_layout_blocks, tile_layout_compact;
   vp9hip_coeff_region regions[64 * 3];
   int n_regions;
   int creating;
@@ -295,7 +295,8 @@ uint32_t *vp9hip_shim_block_off_buffer(struct VP9Decoder *pbi, int n_blocks) {
   return s->block_off;
 }
 
-void vp9hip_shim_set_tile_layout(struct VP9Decoder *pbi, int n_blocks, int n_regions, const int64_t *start, const int64_t *count) {
+void vp9hip_shim_set_tile_layout(struct VP9Decoder *pbi, int n_blocks, int n_regions, const int64_t *start, const int64_t *count,
+                                 int flags) {
   shim_state *s = state_of(pbi, &pbi->common);
   if (!s) return;
   s->tile_layout_blocks = -1;
@@ -309,6 +310,7 @@ void vp9hip_shim_set_tile_layout(struct VP9Decoder *pbi, int n_blocks, int n_reg
       g->start = start[3 * t + p];
       g->count = count[3 * t + p];
     }
+  s->tile_layout_compact = (flags & VP9HIP_SHIM_COEFF_COMPACT) != 0;
   s->tile_layout_blocks = n_blocks;
 }
 
@@ -514,6 +516,7 @@ static int begin_frame(shim_state *s, VP9_COMMON *cm, VP9Decoder *pbi, int *size
       L.total = base;
       L.regions = s->regions;
       L.n_regions = s->n_regions;
+      L.compact = s->tile_layout_compact;
       s->tile_layout_blocks = -1; /* consumed */
     }
     const int persistent = s->frame_mem[0] && dq[0] == (const int32_t *)s->frame_mem[0] && dq[1] == (const int32_t *)s->frame_mem[1] &&

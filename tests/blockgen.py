@@ -183,3 +183,80 @@ def gen_coeffs(rng, blocks, width, height, bd, eob_stride_pad=0, amp=1.0, lossle
                     coef[p].append(blk.ravel())
     coef = [np.concatenate(c).astype(np.int32) if c else np.zeros(0, np.int32) for c in coef]
     return coef, eob
+
+
+# intra_mode_to_tx_type_lookup (libvpx/vp9/common/vp9_blockd.h / vp9_entropy: DC and D45 are DCT_DCT)
+_MODE_IS_DCT = {0: True, 3: True}
+
+
+def coeff_rows(eob, tx_type_is_dct, tx):
+    """The reference's clearing rule (vp9_decodeframe.c:960-967): rows of the block that can be non-zero."""
+    n = 4 << tx
+    if eob <= 0:
+        return 0
+    if eob == 1:
+        return 1
+    if tx_type_is_dct and tx <= 2 and eob <= 10:
+        return 4
+    if tx == 3 and eob <= 34:
+        return 8
+    return n
+
+
+def compact_layout(blocks, coef, eob, width, height, lossless=False, gaps=(5, 0, 3), split=True):
+    """From gen_coeffs' full slots to the compact, caller-placed layout (vp9hip_coeff_layout.compact, E12):
+    every transform block's slot shrinks to the rows the clearing rule leaves, eob-0 blocks take nothing, and
+    each plane's slots sit in one or two regions (a gap before each, as tile columns leave).
+    Returns (coef_compact[3], tile_layout dict for Packer.pack / Decoder.begin_frame, full_offsets, extents)."""
+    aw, ah = (width + 7) & ~7, (height + 7) & ~7
+    mi_rows, mi_cols = ah // 8, aw // 8
+    nb = len(blocks)
+    block_off = np.zeros((nb, 3), np.uint32)
+    out = [[np.zeros(g, np.int32) + 77] for g in gaps]      # garbage in the gaps
+    pos = [g for g in gaps]
+    starts = [[g] for g in gaps]
+    ends = [[] for _ in gaps]
+    run_full = [0, 0, 0]
+    for i, b in enumerate(blocks):
+        if split and i == nb // 2:
+            for p in range(3):
+                ends[p].append(pos[p])
+                out[p].append(np.zeros(7, np.int32) - 99)
+                pos[p] += 7
+                starts[p].append(pos[p])
+        for p in range(3):
+            block_off[i, p] = pos[p]
+        if b["skip"]:
+            continue
+        sbt = int(b["sb_type"])
+        inter = int(b["ref_frame"][0]) > 0
+        bw8, bh8 = max(1, W4[sbt] >> 1), max(1, H4[sbt] >> 1)
+        for p in range(3):
+            ss = 1 if p else 0
+            n4w, n4h = max(1, (bw8 * 2) >> ss), max(1, (bh8 * 2) >> ss)
+            tx = uv_tx(sbt, b["tx_size"]) if p else int(b["tx_size"])
+            vis_w = min(n4w, ((mi_cols - int(b["mi_col"])) * 8 >> ss) // 4)
+            vis_h = min(n4h, ((mi_rows - int(b["mi_row"])) * 8 >> ss) // 4)
+            n = 4 << tx
+            for row in range(0, vis_h, 1 << tx):
+                for col in range(0, vis_w, 1 << tx):
+                    x = ((int(b["mi_col"]) * 8) >> ss) + 4 * col
+                    y = ((int(b["mi_row"]) * 8) >> ss) + 4 * row
+                    e = int(eob[p][y, x])
+                    is_dct = True
+                    if not inter and not lossless and p == 0:
+                        m = int(b["sub_mode"][(row << 1) + col]) if sbt < 3 else int(b["mode"])
+                        is_dct = _MODE_IS_DCT.get(m, False)
+                    ext = coeff_rows(e, is_dct, tx) * n
+                    full = coef[p][run_full[p]:run_full[p] + n * n]
+                    assert not full[ext:].any(), "generator broke the clearing-rule invariant"
+                    out[p].append(full[:ext])
+                    pos[p] += ext
+                    run_full[p] += n * n
+    for p in range(3):
+        ends[p].append(pos[p])
+    coef_c = [np.concatenate(o + [np.zeros(4, np.int32)]).astype(np.int32) for o in out]
+    plane_base = [0, len(coef_c[0]), len(coef_c[0]) + len(coef_c[1])]
+    regions = [(p, s, e - s) for p in range(3) for s, e in zip(starts[p], ends[p])]
+    layout = dict(block_off=block_off, plane_base=plane_base, total=sum(len(c) for c in coef_c), regions=regions, compact=True)
+    return coef_c, layout
