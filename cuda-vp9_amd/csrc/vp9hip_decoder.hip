@@ -290,10 +290,34 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
   } else {
     DEC_HIP(dec, hipEventSynchronize(S->uploaded));  // begun but never run
   }
-  int rc = vp9hip_pack_frame(S->pk, params, blocks, n_blocks, layout, &S->packed);
-  if (rc) DEC_FAIL(dec, rc, "%s", vp9hip_packer_error(S->pk));
-  const vp9hip_packed *P = &S->packed;
   const hipStream_t cs = dec->copy_stream;
+  int rc;
+  // slots placed by the caller (block_off): where they go on the device does not depend on the packer, so the
+  // coefficients — the bulk of a frame's bytes — start travelling before the lists are built
+  static const bool late_env = getenv("VP9HIP_LATE_COEFF_UPLOAD") != nullptr;  // measurement aid: upload after packing
+  const bool early = dqcoeff && layout->block_off && !late_env;
+  if (early) {
+    if (layout->total < 0 || layout->total > (int64_t)UINT32_MAX)
+      DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: bad coefficient total");
+    if ((rc = dv_reserve(dec, &S->d_coeffs, sizeof(int32_t) * (size_t)(layout->total + 16)))) return rc;
+    for (int64_t r = 0; r < layout->n_regions; ++r) {
+      const vp9hip_coeff_region *g = &layout->regions[r];
+      if (g->plane < 0 || g->plane > 2 || g->start < 0 || g->count < 0 ||
+          layout->plane_base[g->plane] < 0 || layout->plane_base[g->plane] + g->start + g->count > layout->total || !dqcoeff[g->plane]) {
+        (void)hipStreamSynchronize(cs);
+        DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: coefficient region %lld out of range", (long long)r);
+      }
+      if (g->count)
+        DEC_HIP(dec, hipMemcpyAsync((int32_t *)S->d_coeffs.p + layout->plane_base[g->plane] + g->start, dqcoeff[g->plane] + g->start,
+                                    sizeof(int32_t) * (size_t)g->count, hipMemcpyHostToDevice, cs));
+    }
+  }
+  rc = vp9hip_pack_frame(S->pk, params, blocks, n_blocks, layout, &S->packed);
+  if (rc) {
+    if (early) (void)hipStreamSynchronize(cs);  // the caller's arrays are its own again
+    DEC_FAIL(dec, rc, "%s", vp9hip_packer_error(S->pk));
+  }
+  const vp9hip_packed *P = &S->packed;
   S->params = *params;
   if ((rc = dv_upload_on(dec, &S->d_inter, P->inter, sizeof(vp9hip_inter_task) * (size_t)P->n_inter, cs))) return rc;
   if ((rc = dv_upload_on(dec, &S->d_txb, P->txb, sizeof(vp9hip_txb) * (size_t)P->n_txb, cs))) return rc;
@@ -317,10 +341,11 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
   if (P->island_sb_expected &&
       (rc = dv_upload_on(dec, &S->d_sb_expected, P->island_sb_expected, sizeof(int32_t) * (size_t)P->sb_rows * P->sb_cols, cs)))
     return rc;
-  if ((rc = dv_reserve(dec, &S->d_coeffs, sizeof(int32_t) * (size_t)(P->coeff_total + 16)))) return rc;
+  if (!early && (rc = dv_reserve(dec, &S->d_coeffs, sizeof(int32_t) * (size_t)(P->coeff_total + 16)))) return rc;
   S->have_coeffs = dqcoeff != NULL;
-  if (dqcoeff && layout->block_off) {
-    // slots placed by the caller: copy the stretches it names, each to the mirror of its host position
+  if (early) {
+    if (P->coeff_total != layout->total) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: coefficient total mismatch");
+  } else if (dqcoeff && layout->block_off) {
     for (int64_t r = 0; r < layout->n_regions; ++r) {
       const vp9hip_coeff_region *g = &layout->regions[r];
       if (g->plane < 0 || g->plane > 2 || g->start < 0 || g->count < 0 ||
