@@ -11,7 +11,7 @@ Runs in the development container only (needs oracle/_ref/vpx/{vpxenc_c,vpxdec_c
   3. the reference's vpxdec (CPU wrap_cuda_* bodies) writes the per-frame MD5 list in vpxdec's
      `--md5` format (libvpx/vpxdec.c:285-302, 490-495) — the format of Sony.md5 / netflix.md5.
 Small streams (<= ~200 KB) land in tests/golden/streams/ and are committed; the BASELINE.json-sized
-ones (S-1440, S-2160, S-1080-10) land in tests/streams_big/ (git-ignored, travels to the GPU box).
+ones (S-1440, S-2160, S-2176, S-1080-10) land in tests/streams_big/ (git-ignored, travels to the GPU box).
 
     python3 tests/golden/streams/make_streams.py [--big] [name ...]
 """
@@ -48,6 +48,8 @@ STREAMS = {
     # BASELINE.json-sized streams (SURVEY §8d / BASELINE.md §2)
     "S-1440": (2560, 1440, 60, 1440, 5, 3, 8, "420", 0.1, 0, ["--cpu-used=2", "--cq-level=24", "--tile-columns=3", "--lag-in-frames=0", "--passes=1"], True),
     "S-2160": (3840, 2160, 30, 2160, 23, -17, 8, "420", 0.0, 8, ["--cpu-used=4", "--cq-level=32", "--tile-columns=4", "--lag-in-frames=0", "--passes=1"], True),
+    # BASELINE.json config 1's exact geometry (FoodMarket2: 3840x2176 = 60x34 whole superblocks), two-pass with alt-ref
+    "S-2176": (3840, 2176, 12, 2176, 9, -5, 8, "420", 0.1, 0, ["--good", "--cpu-used=4", "--cq-level=30", "--tile-columns=4", "--passes=2", "--auto-alt-ref=1", "--lag-in-frames=8"], True),
     "S-1080-10": (1920, 1080, 30, 1080, 7, 4, 10, "420", 0.1, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=2", "--cq-level=28", "--tile-columns=2", "--lag-in-frames=0", "--passes=1"], True),
 }
 

@@ -77,9 +77,9 @@ def test_stream_md5_unchanged_reference_driver():
     check(HIP_A, SMALL, "s704_10")
 
 
-@pytest.mark.parametrize("name", ["S-1440", "S-2160", "S-1080-10"])
+@pytest.mark.parametrize("name", ["S-1440", "S-2160", "S-2176", "S-1080-10"])
 def test_baseline_sized_stream_md5(name):
     if not os.path.exists(os.path.join(BIG, name + ".ivf")):
         pytest.skip(f"tests/streams_big/{name}.ivf not generated (make_streams.py --big)")
     check(HIP, BIG, name)
-    check(HIP_MT, BIG, name)  # 8 / 8 / 16 tile columns
+    check(HIP_MT, BIG, name)  # 8 / 16 / 16 / 4 tile columns
