@@ -1,0 +1,381 @@
+/*
+ * vp9hip_dec — a VP9 decoder built only from this repository: IVF container -> vp9hip_fe (bitstream front-end,
+ * CPU) -> vp9hip_decoder (reconstruction on the GPU: inter prediction, inverse transforms, intra prediction,
+ * loop filter) -> frames / per-frame MD5s in vpxdec's format.  No libvpx on either side.
+ *
+ *   vp9hip_dec [--md5] [-o pattern] [--noblit] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] file.ivf
+ *
+ * --md5 with -o 'img-%wx%h-%4.i420' prints what `vpxdec --rawvideo --md5 -o img-%wx%h-%4.i420` prints (vpxdec.c:285-302,
+ * 1036-1042): one MD5 per shown frame over its visible samples (2 bytes each above 8 bits).  Without --md5 and
+ * with -o the frames are written to the files the pattern names.  --summary prints vpxdec's line
+ * (vpxdec.c:358-363) with the time spent decoding (file reading and hashing excluded).
+ *
+ * Frames are pipelined unless --serial: while the GPU reconstructs frame N the CPU parses frame N+1 (two sets of
+ * coefficient arrays in page-locked memory); a frame is waited for and fetched just before the next one is
+ * handed to the GPU.  A frame that is not shown is never fetched.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "vp9hip_decoder.h"
+#include "vp9hip_fe.h"
+
+/* ---- MD5 (RFC 1321) ------------------------------------------------------------------------------------ */
+typedef struct {
+  uint32_t s[4];
+  uint64_t len;
+  uint8_t buf[64];
+  int fill;
+} Md5;
+static const uint32_t kMd5K[64] = {
+  0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1,
+  0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453,
+  0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942,
+  0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05,
+  0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d,
+  0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391
+};
+static const uint8_t kMd5R[64] = { 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20,
+                                   4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21 };
+static void md5_block(Md5 *m, const uint8_t *p) {
+  uint32_t w[16], a = m->s[0], b = m->s[1], c = m->s[2], d = m->s[3];
+  for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+  for (int i = 0; i < 64; ++i) {
+    uint32_t f;
+    int g;
+    if (i < 16) {
+      f = (b & c) | (~b & d);
+      g = i;
+    } else if (i < 32) {
+      f = (d & b) | (~d & c);
+      g = (5 * i + 1) & 15;
+    } else if (i < 48) {
+      f = b ^ c ^ d;
+      g = (3 * i + 5) & 15;
+    } else {
+      f = c ^ (b | ~d);
+      g = (7 * i) & 15;
+    }
+    const uint32_t x = a + f + kMd5K[i] + w[g];
+    a = d;
+    d = c;
+    c = b;
+    b = b + ((x << kMd5R[i]) | (x >> (32 - kMd5R[i])));
+  }
+  m->s[0] += a;
+  m->s[1] += b;
+  m->s[2] += c;
+  m->s[3] += d;
+}
+static void md5_init(Md5 *m) {
+  m->s[0] = 0x67452301;
+  m->s[1] = 0xefcdab89;
+  m->s[2] = 0x98badcfe;
+  m->s[3] = 0x10325476;
+  m->len = 0;
+  m->fill = 0;
+}
+static void md5_update(Md5 *m, const uint8_t *p, size_t n) {
+  m->len += n;
+  while (n) {
+    if (m->fill == 0 && n >= 64) {
+      md5_block(m, p);
+      p += 64;
+      n -= 64;
+      continue;
+    }
+    size_t k = 64 - (size_t)m->fill;
+    if (k > n) k = n;
+    memcpy(m->buf + m->fill, p, k);
+    m->fill += (int)k;
+    p += k;
+    n -= k;
+    if (m->fill == 64) {
+      md5_block(m, m->buf);
+      m->fill = 0;
+    }
+  }
+}
+static void md5_final(Md5 *m, uint8_t out[16]) {
+  const uint64_t bits = m->len * 8;
+  const uint8_t pad = 0x80, zero = 0;
+  md5_update(m, &pad, 1);
+  while (m->fill != 56) md5_update(m, &zero, 1);
+  uint8_t l[8];
+  for (int i = 0; i < 8; ++i) l[i] = (uint8_t)(bits >> (8 * i));
+  md5_update(m, l, 8);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) out[4 * i + j] = (uint8_t)(m->s[i] >> (8 * j));
+}
+
+/* ---- helpers ------------------------------------------------------------------------------------------- */
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void *pinned_alloc(void *user, size_t bytes) { return vp9hip_decoder_host_alloc((vp9hip_decoder *)user, bytes); }
+static void pinned_free(void *user, void *p) { vp9hip_decoder_host_free((vp9hip_decoder *)user, p); }
+
+static void make_name(const char *pattern, char *out, size_t cap, int w, int h, int frame) { /* generate_filename, vpxdec.c:423 */
+  size_t o = 0;
+  for (const char *p = pattern; *p && o + 16 < cap; ++p) {
+    if (*p != '%') {
+      out[o++] = *p;
+      continue;
+    }
+    ++p;
+    if (*p == 'w')
+      o += (size_t)snprintf(out + o, cap - o, "%d", w);
+    else if (*p == 'h')
+      o += (size_t)snprintf(out + o, cap - o, "%d", h);
+    else if (*p >= '1' && *p <= '9')
+      o += (size_t)snprintf(out + o, cap - o, "%0*d", *p - '0', frame);
+    else
+      out[o++] = *p;
+  }
+  out[o] = 0;
+}
+
+typedef struct {
+  vp9hip_decoder *dec;
+  uint8_t *host[3];
+  size_t host_cap[3];
+  int do_md5, noblit, frame_out;
+  const char *pattern;
+  double t_fetch, t_hash;
+} Output;
+
+/* fetch pool slot `slot` and deliver it the way vpxdec does */
+static int deliver(Output *o, int slot, const vp9hip_frame_params *P) {
+  if (o->noblit && !o->do_md5) {
+    ++o->frame_out;
+    return 0;
+  }
+  const double t0 = now_s();
+  const int bps = P->hbd ? 2 : 1;
+  const int aw = (P->width + 7) & ~7, ah = (P->height + 7) & ~7;
+  vp9hip_host_frame hf;
+  memset(&hf, 0, sizeof(hf));
+  for (int p = 0; p < 3; ++p) {
+    const int ss = p ? P->ss_x : 0;
+    const size_t need = (size_t)(aw >> ss) * (size_t)(ah >> ss) * (size_t)bps;
+    if (need > o->host_cap[p]) {
+      if (o->host[p]) vp9hip_decoder_host_free(o->dec, o->host[p]);
+      o->host[p] = (uint8_t *)vp9hip_decoder_host_alloc(o->dec, need);
+      o->host_cap[p] = o->host[p] ? need : 0;
+      if (!o->host[p]) return -1;
+    }
+    hf.plane[p] = o->host[p];
+    hf.stride[p] = aw >> ss;
+  }
+  hf.width = P->width;
+  hf.height = P->height;
+  hf.ss_x = P->ss_x;
+  hf.ss_y = P->ss_y;
+  hf.bit_depth = P->bit_depth;
+  hf.hbd = P->hbd;
+  if (vp9hip_decoder_download(o->dec, slot, &hf)) {
+    fprintf(stderr, "vp9hip_dec: %s\n", vp9hip_decoder_error(o->dec));
+    return -1;
+  }
+  const double t1 = now_s();
+  o->t_fetch += t1 - t0;
+  ++o->frame_out;
+  char name[512];
+  make_name(o->pattern ? o->pattern : "img-%wx%h-%4.i420", name, sizeof(name), P->width, P->height, o->frame_out);
+  Md5 m;
+  FILE *f = NULL;
+  if (o->do_md5)
+    md5_init(&m);
+  else if (!(f = fopen(name, "wb")))
+    return -1;
+  for (int p = 0; p < 3; ++p) {
+    const int ss = p ? P->ss_x : 0;
+    const int w = ((P->width + ss) >> ss) * bps, hh = (P->height + ss) >> ss;
+    for (int y = 0; y < hh; ++y) {
+      const uint8_t *row = o->host[p] + (size_t)y * (size_t)hf.stride[p] * (size_t)bps;
+      if (o->do_md5)
+        md5_update(&m, row, (size_t)w);
+      else
+        fwrite(row, 1, (size_t)w, f);
+    }
+  }
+  if (o->do_md5) {
+    uint8_t d[16];
+    md5_final(&m, d);
+    for (int i = 0; i < 16; ++i) printf("%02x", d[i]);
+    printf("  %s\n", name);
+  } else {
+    fclose(f);
+  }
+  o->t_hash += now_s() - t1;
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  const char *path = NULL, *pattern = NULL;
+  int do_md5 = 0, noblit = 0, summary = 0, loops = 1, threads = 0, serial = 0, stats = 0;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--md5"))
+      do_md5 = 1;
+    else if (!strcmp(argv[i], "--noblit"))
+      noblit = 1;
+    else if (!strcmp(argv[i], "--summary"))
+      summary = 1;
+    else if (!strcmp(argv[i], "--serial"))
+      serial = 1;
+    else if (!strcmp(argv[i], "--stats"))
+      stats = 1;
+    else if (!strcmp(argv[i], "--rawvideo") || !strcmp(argv[i], "--i420"))
+      ;
+    else if (!strncmp(argv[i], "--loops=", 8))
+      loops = atoi(argv[i] + 8);
+    else if (!strncmp(argv[i], "--threads=", 10))
+      threads = atoi(argv[i] + 10);
+    else if (!strcmp(argv[i], "-o") && i + 1 < argc)
+      pattern = argv[++i];
+    else if (argv[i][0] != '-')
+      path = argv[i];
+    else {
+      fprintf(stderr, "vp9hip_dec: unknown option %s\n", argv[i]);
+      return 2;
+    }
+  }
+  if (!path) {
+    fprintf(stderr, "usage: vp9hip_dec [--md5] [-o pattern] [--noblit] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] file.ivf\n");
+    return 2;
+  }
+  if (!pattern && !do_md5) noblit = 1;
+  FILE *f = fopen(path, "rb");
+  if (!f) {
+    perror(path);
+    return 1;
+  }
+  fseek(f, 0, SEEK_END);
+  const long fsz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  uint8_t *file = (uint8_t *)malloc((size_t)fsz + 8);
+  if (!file || fread(file, 1, (size_t)fsz, f) != (size_t)fsz) {
+    fprintf(stderr, "vp9hip_dec: cannot read %s\n", path);
+    return 1;
+  }
+  fclose(f);
+  if (fsz < 32 || memcmp(file, "DKIF", 4) || memcmp(file + 8, "VP90", 4)) {
+    fprintf(stderr, "vp9hip_dec: %s is not a VP9 IVF file\n", path);
+    return 1;
+  }
+  const size_t hdr = (size_t)file[6] | ((size_t)file[7] << 8);
+
+  vp9hip_decoder *dec = NULL;
+  if (vp9hip_decoder_create(0, &dec)) {
+    fprintf(stderr, "vp9hip_dec: no HIP device / decoder (%s)\n", dec ? vp9hip_decoder_error(dec) : "create failed");
+    return 1;
+  }
+  vp9hip_decoder_set_timing(dec, 0);
+  int rc_all = 0;
+  for (int loop = 0; loop < loops && !rc_all; ++loop) {
+    /* a new stream per loop; the front-end's coefficient arrays (two sets, alternating) are page-locked */
+    vp9hip_fe *fe[1] = { NULL };
+    if (vp9hip_fe_create(&fe[0], pinned_alloc, pinned_free, dec, threads)) return 1;
+    Output out;
+    memset(&out, 0, sizeof(out));
+    out.dec = dec;
+    out.do_md5 = do_md5;
+    out.noblit = noblit;
+    out.pattern = pattern;
+    int frames_in = 0;
+    double t_parse = 0, t_begin = 0, t_wait = 0;
+    const double t_loop = now_s();
+    /* the frame in flight on the GPU */
+    int pend = 0, pend_slot = -1;
+    vp9hip_frame_params pend_params;
+    memset(&pend_params, 0, sizeof(pend_params));
+    size_t pos = hdr;
+    while (pos + 12 <= (size_t)fsz && !rc_all) {
+      const size_t psz = (size_t)file[pos] | ((size_t)file[pos + 1] << 8) | ((size_t)file[pos + 2] << 16) | ((size_t)file[pos + 3] << 24);
+      pos += 12;
+      if (pos + psz > (size_t)fsz) break;
+      uint32_t sizes[8];
+      const int nf = vp9hip_fe_split_superframe(file + pos, psz, sizes);
+      size_t off = 0;
+      for (int k = 0; k < nf && !rc_all; ++k) {
+        /* a one-byte frame inside a superframe is a "skipped" marker of the encoder (vp9_dx_iface.c: decoder_decode) */
+        if (nf > 1 && sizes[k] == 0) continue;
+        vp9hip_fe_frame fr;
+        double t0 = now_s();
+        int rc = vp9hip_fe_parse(fe[0], file + pos + off, sizes[k], &fr);
+        off += sizes[k];
+        t_parse += now_s() - t0;
+        if (rc) {
+          fprintf(stderr, "vp9hip_dec: frame %d: %s\n", frames_in, vp9hip_fe_error(fe[0]));
+          rc_all = 1;
+          break;
+        }
+        ++frames_in;
+        /* the previous frame: wait for it and deliver it before its successor goes to the GPU */
+        t0 = now_s();
+        if (pend) {
+          if (vp9hip_decoder_sync(dec)) {
+            fprintf(stderr, "vp9hip_dec: %s\n", vp9hip_decoder_error(dec));
+            rc_all = 1;
+            break;
+          }
+          t_wait += now_s() - t0;
+          if (pend_slot >= 0 && deliver(&out, pend_slot, &pend_params)) rc_all = 1;
+          pend = 0;
+        }
+        if (fr.show_existing) {
+          if (deliver(&out, fr.show_slot, &fr.params)) rc_all = 1;
+          continue;
+        }
+        t0 = now_s();
+        const vp9hip_frame_params *P = &fr.params;
+        int ok = !vp9hip_decoder_alloc_slot(dec, fr.new_slot, P->width, P->height, P->ss_x, P->bit_depth, P->hbd, 0);
+        ok = ok && !vp9hip_decoder_begin_frame_ex(dec, P, fr.blocks, fr.n_blocks, &fr.layout, fr.dqcoeff, VP9HIP_BEGIN_HOST_PERSISTENT);
+        int phases = VP9HIP_PHASE_INTRA | (fr.key_frame || fr.intra_only ? 0 : VP9HIP_PHASE_INTER) | (fr.filter_level ? VP9HIP_PHASE_LF : 0);
+        ok = ok && !vp9hip_decoder_run(dec, phases, fr.ref_slot, fr.new_slot, NULL, fr.filter_level ? &fr.lf_thresh : NULL);
+        t_begin += now_s() - t0;
+        if (!ok) {
+          fprintf(stderr, "vp9hip_dec: frame %d: %s\n", frames_in, vp9hip_decoder_error(dec));
+          rc_all = 1;
+          break;
+        }
+        pend = 1;
+        pend_slot = fr.show_frame ? fr.new_slot : -1;
+        pend_params = *P;
+        if (serial) {
+          t0 = now_s();
+          if (vp9hip_decoder_sync(dec)) rc_all = 1;
+          t_wait += now_s() - t0;
+          if (!rc_all && pend_slot >= 0 && deliver(&out, pend_slot, &pend_params)) rc_all = 1;
+          pend = 0;
+        }
+      }
+      pos += psz;
+    }
+    if (pend && !rc_all) {
+      if (vp9hip_decoder_sync(dec)) rc_all = 1;
+      if (!rc_all && pend_slot >= 0 && deliver(&out, pend_slot, &pend_params)) rc_all = 1;
+    }
+    const double dt = now_s() - t_loop - out.t_hash;
+    if (summary)
+      fprintf(stderr, "%d decoded frames/%d showed frames in %.0f us (%.2f fps)\n", frames_in, out.frame_out, dt * 1e6,
+              out.frame_out / (dt > 0 ? dt : 1));
+    if (stats)
+      fprintf(stderr, "vp9hip_dec: per frame: parse %.3f ms, pack + launch %.3f ms, wait %.3f ms, fetch %.3f ms, hash/write %.3f ms\n",
+              1e3 * t_parse / frames_in, 1e3 * t_begin / frames_in, 1e3 * t_wait / frames_in, 1e3 * out.t_fetch / frames_in,
+              1e3 * out.t_hash / frames_in);
+    for (int p = 0; p < 3; ++p)
+      if (out.host[p]) vp9hip_decoder_host_free(dec, out.host[p]);
+    vp9hip_decoder_sync(dec);
+    vp9hip_fe_destroy(fe[0]);
+  }
+  vp9hip_decoder_destroy(dec);
+  free(file);
+  return rc_all;
+}

@@ -387,6 +387,58 @@ static void intra_block(oracle_state *s, VP9_COMMON *cm, MACROBLOCKD *xd, MODE_I
   })
 }
 
+/* VP9_ORACLE_DUMP_BLOCKS=<file>: the parsed mode information of every frame, one 64-byte record per block in decode
+ * order (the layout of vp9hip_block, include/vp9hip_pack.h) — what tests/test_fe_blocks.py compares the product's
+ * own bitstream front-end with.  reserved[0] segment id, reserved[2] the skip flag as parsed, reserved2: a
+ * checksum over the block's eobs and coefficients. */
+static FILE *g_dump;
+static void dump_block(oracle_state *s, VP9_COMMON *cm, MACROBLOCKD *xd, MODE_INFO *mi, int index, int mi_row, int mi_col,
+                       const tran_high_t *const res[3], tran_low_t *dq[3]) {
+  unsigned char rec[64];
+  (void)res;
+  memset(rec, 0, sizeof(rec));
+  const int parsed_skip = s->parsed_valid ? s->parsed_skip[index] : (mi->skip != 0);
+  const short pos[2] = { (short)mi_row, (short)mi_col };
+  memcpy(rec, pos, 4);
+  rec[4] = (unsigned char)mi->sb_type;
+  rec[5] = (unsigned char)mi->tx_size;
+  rec[6] = (unsigned char)(mi->skip != 0);
+  rec[7] = (unsigned char)mi->interp_filter;
+  rec[8] = (unsigned char)mi->ref_frame[0];
+  rec[9] = (unsigned char)mi->ref_frame[1];
+  rec[10] = (unsigned char)mi->mode;
+  rec[11] = (unsigned char)mi->uv_mode;
+  for (int i = 0; i < 4; ++i) rec[12 + i] = (unsigned char)mi->bmi[i].as_mode;
+  {
+    static const unsigned char lut[14] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 1 }; /* mode_lf_lut, vp9_loopfilter.c:207 */
+    rec[16] = cm->lf.filter_level ? cm->lf_info.lvl[mi->segment_id][mi->ref_frame[0]][lut[mi->mode]] : 0;
+  }
+  rec[17] = (unsigned char)mi->segment_id;
+  rec[19] = (unsigned char)parsed_skip;
+  for (int r = 0; r < 2; ++r) {
+    const short mv[2] = { mi->mv[r].as_mv.row, mi->mv[r].as_mv.col };
+    memcpy(rec + 20 + 4 * r, mv, 4);
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 2; ++r) {
+      const short mv[2] = { mi->bmi[i].as_mv[r].as_mv.row, mi->bmi[i].as_mv[r].as_mv.col };
+      memcpy(rec + 28 + 8 * i + 4 * r, mv, 4);
+    }
+  unsigned cs = 0;
+  if (s->attached && !parsed_skip) {
+    FOREACH_TXB(xd, mi, t, {
+      const int eob = eob_at(s, xd, &t, mi_row, mi_col);
+      unsigned sum = 0;
+      if (eob > 0)
+        for (int i = 0; i < t.n; ++i) sum += (unsigned)dq[t.plane][i] * (unsigned)(i + 1);
+      cs = cs * 1000003u + sum + (unsigned)eob * 7919u;
+      dq[t.plane] += t.n;
+    })
+  }
+  memcpy(rec + 60, &cs, 4);
+  fwrite(rec, 1, sizeof(rec), g_dump);
+}
+
 static void reserve_parsed(oracle_state *s, const VP9_COMMON *cm, const int *size_for_mb) {
   const int n_sb = ((cm->mi_rows + 7) >> 3) * ((cm->mi_cols + 7) >> 3);
   int n = 0;
@@ -441,6 +493,15 @@ int wrap_cuda_intra_prediction(double *gpu_copy, double *gpu_run, int *size_for_
   if (!s->attached) {
     if (!(cur->flags & YV12_FLAG_HIGHBITDEPTH)) die("residual-plane mode needs a high-bitdepth frame buffer (as the reference does)");
     for (int p = 0; p < 3; ++p) res[p] = frameBuffer->plane_residuals[p];
+  }
+  if (!g_dump && getenv("VP9_ORACLE_DUMP_BLOCKS")) g_dump = fopen(getenv("VP9_ORACLE_DUMP_BLOCKS"), "wb");
+  if (g_dump) {
+    const int n_sb = ((cm->mi_rows + 7) >> 3) * ((cm->mi_cols + 7) >> 3);
+    int hdr[4] = { 0x56503946, 0, cm->width, cm->height };
+    for (int i = 0; i < n_sb; ++i) hdr[1] += size_for_mb[i];
+    fwrite(hdr, sizeof(int), 4, g_dump);
+    walk_blocks(s, cm, pbi, size_for_mb, MiBuf, tile_rows, tile_cols, res, dump_block);
+    fflush(g_dump);
   }
   walk_blocks(s, cm, pbi, size_for_mb, MiBuf, tile_rows, tile_cols, res, intra_block);
   s->parsed_valid = 0;
