@@ -117,8 +117,8 @@ fi
 # ---- the format's constant tables of the product's bitstream front-end: regenerate from the reference's objects and
 # compare with the committed file (cuda-vp9_amd/csrc/fe/vp9fe_tables.inc)
 gcc -std=gnu99 -O1 -w $INC -include "$OUT/simd_to_c.h" "$HERE/dump_vp9_tables.c" "$OUT/libvpxfull.a" -lm -lpthread -o "$OUT/tools/dump_vp9_tables"
-"$OUT/tools/dump_vp9_tables" > "$TMP/vp9fe_tables.inc"
-if ! cmp -s "$TMP/vp9fe_tables.inc" "$ROOT/cuda-vp9_amd/csrc/fe/vp9fe_tables.inc"; then
+"$OUT/tools/dump_vp9_tables" > "$OUT/vp9fe_tables.check"
+if ! cmp -s "$OUT/vp9fe_tables.check" "$ROOT/cuda-vp9_amd/csrc/fe/vp9fe_tables.inc"; then
   echo "build_refvpx: cuda-vp9_amd/csrc/fe/vp9fe_tables.inc differs from what the reference's objects hold"; exit 1
 fi
 echo "built $OUT/{vpxdec_cA,vpxdec_c,vpxenc_c}; vp9fe_tables.inc verified"
