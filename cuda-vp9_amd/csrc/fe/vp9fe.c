@@ -227,15 +227,23 @@ struct vp9hip_fe {
   uint32_t (*seg_off)[3];
   int32_t *grid;                /* index into seg_blocks per 8x8 cell, -1 = not decoded */
   int32_t *sb_count;            /* blocks per superblock */
-  size_t cells_cap;
+  size_t cells_cap, sb_cap;
   vp9hip_block *out_blocks;     /* merged list (several tile columns) */
   uint32_t *out_off;
   int32_t *eob[3];
   size_t eob_cap[3];
-  int32_t *coef[3];             /* the set this frame writes; coef_other: the previous frame's, possibly still travelling */
-  int32_t *coef_other[3];
+  int32_t *coef[3];
   size_t coef_cap[3];
-  vp9hip_coeff_region regions[3 * MAX_TILE_COLS];
+  /* the output arrays above are aliases of one of three sets used in rotation: a caller may still be packing frame
+   * N - 1 and the device fetching the coefficients of frame N - 2 while frame N is parsed */
+  struct OutSet {
+    vp9hip_block *seg_blocks, *out_blocks;
+    uint32_t (*seg_off)[3];
+    uint32_t *out_off;
+    int32_t *eob[3], *coef[3];
+    vp9hip_coeff_region regions[3 * MAX_TILE_COLS];
+  } sets[3];
+  int set_idx;
 
   /* thread pool */
   pthread_t thr[16];
@@ -1945,16 +1953,29 @@ int vp9hip_fe_create(vp9hip_fe **out, vp9hip_alloc_fn alloc, vp9hip_free_fn rele
 }
 
 static void coef_free(vp9hip_fe *fe, int p) {
-  int32_t **sets[2] = { &fe->coef[p], &fe->coef_other[p] };
-  for (int k = 0; k < 2; ++k) {
-    if (!*sets[k]) continue;
+  for (int k = 0; k < 3; ++k) {
+    if (!fe->sets[k].coef[p]) continue;
     if (fe->release)
-      fe->release(fe->user, *sets[k]);
+      fe->release(fe->user, fe->sets[k].coef[p]);
     else
-      free(*sets[k]);
-    *sets[k] = NULL;
+      free(fe->sets[k].coef[p]);
+    fe->sets[k].coef[p] = NULL;
   }
+  fe->coef[p] = NULL;
   fe->coef_cap[p] = 0;
+}
+
+static void use_set(vp9hip_fe *fe, int k) {
+  const struct OutSet *s = &fe->sets[k];
+  fe->set_idx = k;
+  fe->seg_blocks = s->seg_blocks;
+  fe->out_blocks = s->out_blocks;
+  fe->seg_off = s->seg_off;
+  fe->out_off = s->out_off;
+  for (int p = 0; p < 3; ++p) {
+    fe->eob[p] = s->eob[p];
+    fe->coef[p] = s->coef[p];
+  }
 }
 
 void vp9hip_fe_destroy(vp9hip_fe *fe) {
@@ -1969,16 +1990,18 @@ void vp9hip_fe_destroy(vp9hip_fe *fe) {
   pthread_cond_destroy(&fe->cv_done);
   for (int p = 0; p < 3; ++p) {
     coef_free(fe, p);
-    free(fe->eob[p]);
+    for (int k = 0; k < 3; ++k) free(fe->sets[k].eob[p]);
     free(fe->above_nz[p]);
   }
+  for (int k = 0; k < 3; ++k) {
+    free(fe->sets[k].seg_blocks);
+    free(fe->sets[k].seg_off);
+    free(fe->sets[k].out_blocks);
+    free(fe->sets[k].out_off);
+  }
   free(fe->above_part);
-  free(fe->seg_blocks);
-  free(fe->seg_off);
   free(fe->grid);
   free(fe->sb_count);
-  free(fe->out_blocks);
-  free(fe->out_off);
   free(fe->seg_map[0]);
   free(fe->seg_map[1]);
   free(fe->mvs[0]);
@@ -2025,39 +2048,57 @@ static int ensure_frame_arrays(vp9hip_fe *fe) {
     fe->ctx_cols = ctx_cols;
   }
   if (cells > fe->cells_cap) {
-    free(fe->seg_blocks);
-    free(fe->seg_off);
+    int ok = 1;
+    for (int k = 0; k < 3; ++k) {
+      struct OutSet *s = &fe->sets[k];
+      free(s->seg_blocks);
+      free(s->seg_off);
+      free(s->out_blocks);
+      free(s->out_off);
+      s->seg_blocks = (vp9hip_block *)malloc(sizeof(vp9hip_block) * (cells + 1));
+      s->seg_off = (uint32_t(*)[3])malloc(sizeof(uint32_t) * 3 * (cells + 1));
+      s->out_blocks = (vp9hip_block *)malloc(sizeof(vp9hip_block) * (cells + 1));
+      s->out_off = (uint32_t *)malloc(sizeof(uint32_t) * 3 * (cells + 1));
+      ok &= s->seg_blocks && s->seg_off && s->out_blocks && s->out_off;
+    }
     free(fe->grid);
     free(fe->sb_count);
-    free(fe->out_blocks);
-    free(fe->out_off);
-    fe->seg_blocks = (vp9hip_block *)malloc(sizeof(vp9hip_block) * (cells + 1));
-    fe->seg_off = (uint32_t(*)[3])malloc(sizeof(uint32_t) * 3 * (cells + 1));
     fe->grid = (int32_t *)malloc(sizeof(int32_t) * (cells + 1));
     fe->sb_count = (int32_t *)malloc(sizeof(int32_t) * ((size_t)(ctx_cols >> 3) * (ctx_rows >> 3) + 1));
-    fe->out_blocks = (vp9hip_block *)malloc(sizeof(vp9hip_block) * (cells + 1));
-    fe->out_off = (uint32_t *)malloc(sizeof(uint32_t) * 3 * (cells + 1));
-    fe->cells_cap = (fe->seg_blocks && fe->seg_off && fe->grid && fe->sb_count && fe->out_blocks && fe->out_off) ? cells : 0;
+    fe->cells_cap = (ok && fe->grid && fe->sb_count) ? cells : 0;
     if (!fe->cells_cap) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
+  } else if ((size_t)(ctx_cols >> 3) * (ctx_rows >> 3) > fe->sb_cap) {
+    free(fe->sb_count);
+    fe->sb_count = (int32_t *)malloc(sizeof(int32_t) * ((size_t)(ctx_cols >> 3) * (ctx_rows >> 3) + 1));
+    if (!fe->sb_count) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
   }
+  if ((size_t)(ctx_cols >> 3) * (ctx_rows >> 3) > fe->sb_cap) fe->sb_cap = (size_t)(ctx_cols >> 3) * (ctx_rows >> 3);
   for (int p = 0; p < 3; ++p) {
     const int ss = p ? fe->ss_x : 0;
     const size_t pw = (size_t)(ctx_cols * 8) >> ss, ph = (size_t)(ctx_rows * 8) >> ss;
     const size_t want_e = (pw >> 2) * (ph >> 2), want_c = pw * ph + 64;
     if (want_e > fe->eob_cap[p]) {
-      free(fe->eob[p]);
-      fe->eob[p] = (int32_t *)malloc(sizeof(int32_t) * want_e);
-      fe->eob_cap[p] = fe->eob[p] ? want_e : 0;
-      if (!fe->eob[p]) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
+      int ok = 1;
+      for (int k = 0; k < 3; ++k) {
+        free(fe->sets[k].eob[p]);
+        fe->sets[k].eob[p] = (int32_t *)malloc(sizeof(int32_t) * want_e);
+        ok &= fe->sets[k].eob[p] != NULL;
+      }
+      fe->eob_cap[p] = ok ? want_e : 0;
+      if (!ok) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
     }
     if (want_c > fe->coef_cap[p]) {
+      int ok = 1;
       coef_free(fe, p);
-      fe->coef[p] = (int32_t *)(fe->alloc ? fe->alloc(fe->user, sizeof(int32_t) * want_c) : malloc(sizeof(int32_t) * want_c));
-      fe->coef_other[p] = (int32_t *)(fe->alloc ? fe->alloc(fe->user, sizeof(int32_t) * want_c) : malloc(sizeof(int32_t) * want_c));
-      fe->coef_cap[p] = (fe->coef[p] && fe->coef_other[p]) ? want_c : 0;
-      if (!fe->coef_cap[p]) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
+      for (int k = 0; k < 3; ++k) {
+        fe->sets[k].coef[p] = (int32_t *)(fe->alloc ? fe->alloc(fe->user, sizeof(int32_t) * want_c) : malloc(sizeof(int32_t) * want_c));
+        ok &= fe->sets[k].coef[p] != NULL;
+      }
+      fe->coef_cap[p] = ok ? want_c : 0;
+      if (!ok) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
     }
   }
+  use_set(fe, (fe->set_idx + 1) % 3);
   return VP9HIP_OK;
 }
 
@@ -2088,11 +2129,6 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
   const int intra_frame = h->frame_type == KEY_FRAME || h->intra_only;
   if (h->header_bytes + h->first_partition_size > size) FE_FAIL(fe, "truncated packet or corrupt header length");
   if ((rc = ensure_frame_arrays(fe))) return rc;
-  for (int p = 0; p < 3; ++p) { /* the other set of coefficient arrays: the previous frame's may still be on its way to the device */
-    int32_t *tmp = fe->coef[p];
-    fe->coef[p] = fe->coef_other[p];
-    fe->coef_other[p] = tmp;
-  }
 
   /* vp9_decode_frame :3507 */
   fe->use_prev_mvs = !h->error_res && fe->width == fe->last_width && fe->height == fe->last_height && !fe->last_intra_only &&
@@ -2285,14 +2321,14 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
   int nr = 0;
   for (int c = 0; c < tile_cols; ++c)
     for (int p = 0; p < 3; ++p) {
-      vp9hip_coeff_region *g = &fe->regions[nr++];
+      vp9hip_coeff_region *g = &fe->sets[fe->set_idx].regions[nr++];
       g->plane = p;
       g->reserved = 0;
       g->start = jobs[c].cf_start[p];
       g->count = jobs[c].cf_used[p];
       out->coeff_count += g->count;
     }
-  L->regions = fe->regions;
+  L->regions = fe->sets[fe->set_idx].regions;
   L->n_regions = nr;
   return VP9HIP_OK;
 }

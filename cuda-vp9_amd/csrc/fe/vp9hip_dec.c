@@ -3,18 +3,20 @@
  * CPU) -> vp9hip_decoder (reconstruction on the GPU: inter prediction, inverse transforms, intra prediction,
  * loop filter) -> frames / per-frame MD5s in vpxdec's format.  No libvpx on either side.
  *
- *   vp9hip_dec [--md5] [-o pattern] [--noblit] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] file.ivf
+ *   vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] file.ivf
  *
  * --md5 with -o 'img-%wx%h-%4.i420' prints what `vpxdec --rawvideo --md5 -o img-%wx%h-%4.i420` prints (vpxdec.c:285-302,
  * 1036-1042): one MD5 per shown frame over its visible samples (2 bytes each above 8 bits).  Without --md5 and
  * with -o the frames are written to the files the pattern names.  --summary prints vpxdec's line
  * (vpxdec.c:358-363) with the time spent decoding (file reading and hashing excluded).
  *
- * Frames are pipelined unless --serial: while the GPU reconstructs frame N the CPU parses frame N+1 (two sets of
- * coefficient arrays in page-locked memory); a frame is waited for and fetched just before the next one is
- * handed to the GPU.  A frame that is not shown is never fetched.
+ * Frames are pipelined unless --serial: a second thread owns the GPU side — it waits for frame N - 1 and fetches it,
+ * packs frame N and launches its kernels — while the first thread parses frame N + 1 (the front-end rotates three
+ * sets of output arrays, the coefficient arrays in page-locked memory).  A frame that is not shown is never
+ * fetched; --noblit without --md5 fetches nothing unless --fetch is given.
  */
 #define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -145,14 +147,14 @@ typedef struct {
   vp9hip_decoder *dec;
   uint8_t *host[3];
   size_t host_cap[3];
-  int do_md5, noblit, frame_out;
+  int do_md5, noblit, fetch, frame_out;
   const char *pattern;
   double t_fetch, t_hash;
 } Output;
 
 /* fetch pool slot `slot` and deliver it the way vpxdec does */
 static int deliver(Output *o, int slot, const vp9hip_frame_params *P) {
-  if (o->noblit && !o->do_md5) {
+  if (o->noblit && !o->do_md5 && !o->fetch) {
     ++o->frame_out;
     return 0;
   }
@@ -186,6 +188,7 @@ static int deliver(Output *o, int slot, const vp9hip_frame_params *P) {
   const double t1 = now_s();
   o->t_fetch += t1 - t0;
   ++o->frame_out;
+  if (o->noblit && !o->do_md5) return 0;
   char name[512];
   make_name(o->pattern ? o->pattern : "img-%wx%h-%4.i420", name, sizeof(name), P->width, P->height, o->frame_out);
   Md5 m;
@@ -217,14 +220,80 @@ static int deliver(Output *o, int slot, const vp9hip_frame_params *P) {
   return 0;
 }
 
+/* ---- the GPU side: one frame at a time, the previous one delivered just before its successor is launched ---- */
+typedef struct {
+  vp9hip_decoder *dec;
+  Output *out;
+  int pend, pend_slot;
+  vp9hip_frame_params pend_params;
+  double t_begin, t_wait;
+  int failed;
+  /* hand-over from the parsing thread (a rendezvous: the parser waits until the previous frame has been taken care of) */
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  vp9hip_fe_frame frame;
+  int has, quit;
+} Gpu;
+
+static int gpu_flush(Gpu *g) {
+  if (!g->pend) return 0;
+  const double t0 = now_s();
+  if (vp9hip_decoder_sync(g->dec)) {
+    fprintf(stderr, "vp9hip_dec: %s\n", vp9hip_decoder_error(g->dec));
+    return -1;
+  }
+  g->t_wait += now_s() - t0;
+  g->pend = 0;
+  return g->pend_slot >= 0 ? deliver(g->out, g->pend_slot, &g->pend_params) : 0;
+}
+
+static int gpu_frame(Gpu *g, const vp9hip_fe_frame *fr, int serial) {
+  if (gpu_flush(g)) return -1;
+  if (fr->show_existing) return deliver(g->out, fr->show_slot, &fr->params);
+  const double t0 = now_s();
+  const vp9hip_frame_params *P = &fr->params;
+  int ok = !vp9hip_decoder_alloc_slot(g->dec, fr->new_slot, P->width, P->height, P->ss_x, P->bit_depth, P->hbd, 0);
+  ok = ok && !vp9hip_decoder_begin_frame_ex(g->dec, P, fr->blocks, fr->n_blocks, &fr->layout, fr->dqcoeff, VP9HIP_BEGIN_HOST_PERSISTENT);
+  const int phases = VP9HIP_PHASE_INTRA | (fr->key_frame || fr->intra_only ? 0 : VP9HIP_PHASE_INTER) | (fr->filter_level ? VP9HIP_PHASE_LF : 0);
+  ok = ok && !vp9hip_decoder_run(g->dec, phases, fr->ref_slot, fr->new_slot, NULL, fr->filter_level ? &fr->lf_thresh : NULL);
+  g->t_begin += now_s() - t0;
+  if (!ok) {
+    fprintf(stderr, "vp9hip_dec: %s\n", vp9hip_decoder_error(g->dec));
+    return -1;
+  }
+  g->pend = 1;
+  g->pend_slot = fr->show_frame ? fr->new_slot : -1;
+  g->pend_params = *P;
+  return serial ? gpu_flush(g) : 0;
+}
+
+static void *gpu_main(void *arg) {
+  Gpu *g = (Gpu *)arg;
+  pthread_mutex_lock(&g->mu);
+  for (;;) {
+    while (!g->has && !g->quit) pthread_cond_wait(&g->cv, &g->mu);
+    if (!g->has) break;
+    pthread_mutex_unlock(&g->mu);
+    const int rc = g->failed ? 0 : gpu_frame(g, &g->frame, 0);
+    pthread_mutex_lock(&g->mu);
+    if (rc) g->failed = 1;
+    g->has = 0;
+    pthread_cond_broadcast(&g->cv);
+  }
+  pthread_mutex_unlock(&g->mu);
+  return NULL;
+}
+
 int main(int argc, char **argv) {
   const char *path = NULL, *pattern = NULL;
-  int do_md5 = 0, noblit = 0, summary = 0, loops = 1, threads = 0, serial = 0, stats = 0;
+  int do_md5 = 0, noblit = 0, fetch = 0, summary = 0, loops = 1, threads = 0, serial = 0, stats = 0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--md5"))
       do_md5 = 1;
     else if (!strcmp(argv[i], "--noblit"))
       noblit = 1;
+    else if (!strcmp(argv[i], "--fetch"))
+      fetch = 1;
     else if (!strcmp(argv[i], "--summary"))
       summary = 1;
     else if (!strcmp(argv[i], "--serial"))
@@ -247,7 +316,7 @@ int main(int argc, char **argv) {
     }
   }
   if (!path) {
-    fprintf(stderr, "usage: vp9hip_dec [--md5] [-o pattern] [--noblit] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] file.ivf\n");
+    fprintf(stderr, "usage: vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] file.ivf\n");
     return 2;
   }
   if (!pattern && !do_md5) noblit = 1;
@@ -279,22 +348,27 @@ int main(int argc, char **argv) {
   vp9hip_decoder_set_timing(dec, 0);
   int rc_all = 0;
   for (int loop = 0; loop < loops && !rc_all; ++loop) {
-    /* a new stream per loop; the front-end's coefficient arrays (two sets, alternating) are page-locked */
-    vp9hip_fe *fe[1] = { NULL };
-    if (vp9hip_fe_create(&fe[0], pinned_alloc, pinned_free, dec, threads)) return 1;
+    vp9hip_fe *fe = NULL; /* a new stream per loop */
+    if (vp9hip_fe_create(&fe, pinned_alloc, pinned_free, dec, threads)) return 1;
     Output out;
     memset(&out, 0, sizeof(out));
     out.dec = dec;
     out.do_md5 = do_md5;
     out.noblit = noblit;
+    out.fetch = fetch;
     out.pattern = pattern;
+    Gpu g;
+    memset(&g, 0, sizeof(g));
+    g.dec = dec;
+    g.out = &out;
+    pthread_mutex_init(&g.mu, NULL);
+    pthread_cond_init(&g.cv, NULL);
+    pthread_t th;
+    int have_thread = 0;
+    if (!serial && pthread_create(&th, NULL, gpu_main, &g) == 0) have_thread = 1;
     int frames_in = 0;
-    double t_parse = 0, t_begin = 0, t_wait = 0;
+    double t_parse = 0, t_hand = 0;
     const double t_loop = now_s();
-    /* the frame in flight on the GPU */
-    int pend = 0, pend_slot = -1;
-    vp9hip_frame_params pend_params;
-    memset(&pend_params, 0, sizeof(pend_params));
     size_t pos = hdr;
     while (pos + 12 <= (size_t)fsz && !rc_all) {
       const size_t psz = (size_t)file[pos] | ((size_t)file[pos + 1] << 8) | ((size_t)file[pos + 2] << 16) | ((size_t)file[pos + 3] << 24);
@@ -304,76 +378,60 @@ int main(int argc, char **argv) {
       const int nf = vp9hip_fe_split_superframe(file + pos, psz, sizes);
       size_t off = 0;
       for (int k = 0; k < nf && !rc_all; ++k) {
-        /* a one-byte frame inside a superframe is a "skipped" marker of the encoder (vp9_dx_iface.c: decoder_decode) */
         if (nf > 1 && sizes[k] == 0) continue;
         vp9hip_fe_frame fr;
         double t0 = now_s();
-        int rc = vp9hip_fe_parse(fe[0], file + pos + off, sizes[k], &fr);
+        const int rc = vp9hip_fe_parse(fe, file + pos + off, sizes[k], &fr);
         off += sizes[k];
         t_parse += now_s() - t0;
         if (rc) {
-          fprintf(stderr, "vp9hip_dec: frame %d: %s\n", frames_in, vp9hip_fe_error(fe[0]));
+          fprintf(stderr, "vp9hip_dec: frame %d: %s\n", frames_in, vp9hip_fe_error(fe));
           rc_all = 1;
           break;
         }
         ++frames_in;
-        /* the previous frame: wait for it and deliver it before its successor goes to the GPU */
         t0 = now_s();
-        if (pend) {
-          if (vp9hip_decoder_sync(dec)) {
-            fprintf(stderr, "vp9hip_dec: %s\n", vp9hip_decoder_error(dec));
-            rc_all = 1;
-            break;
-          }
-          t_wait += now_s() - t0;
-          if (pend_slot >= 0 && deliver(&out, pend_slot, &pend_params)) rc_all = 1;
-          pend = 0;
-        }
-        if (fr.show_existing) {
-          if (deliver(&out, fr.show_slot, &fr.params)) rc_all = 1;
-          continue;
-        }
-        t0 = now_s();
-        const vp9hip_frame_params *P = &fr.params;
-        int ok = !vp9hip_decoder_alloc_slot(dec, fr.new_slot, P->width, P->height, P->ss_x, P->bit_depth, P->hbd, 0);
-        ok = ok && !vp9hip_decoder_begin_frame_ex(dec, P, fr.blocks, fr.n_blocks, &fr.layout, fr.dqcoeff, VP9HIP_BEGIN_HOST_PERSISTENT);
-        int phases = VP9HIP_PHASE_INTRA | (fr.key_frame || fr.intra_only ? 0 : VP9HIP_PHASE_INTER) | (fr.filter_level ? VP9HIP_PHASE_LF : 0);
-        ok = ok && !vp9hip_decoder_run(dec, phases, fr.ref_slot, fr.new_slot, NULL, fr.filter_level ? &fr.lf_thresh : NULL);
-        t_begin += now_s() - t0;
-        if (!ok) {
-          fprintf(stderr, "vp9hip_dec: frame %d: %s\n", frames_in, vp9hip_decoder_error(dec));
+        if (have_thread) {
+          pthread_mutex_lock(&g.mu);
+          while (g.has) pthread_cond_wait(&g.cv, &g.mu);
+          if (g.failed) rc_all = 1;
+          g.frame = fr;
+          g.has = 1;
+          pthread_cond_broadcast(&g.cv);
+          pthread_mutex_unlock(&g.mu);
+        } else if (gpu_frame(&g, &fr, serial)) {
           rc_all = 1;
-          break;
         }
-        pend = 1;
-        pend_slot = fr.show_frame ? fr.new_slot : -1;
-        pend_params = *P;
-        if (serial) {
-          t0 = now_s();
-          if (vp9hip_decoder_sync(dec)) rc_all = 1;
-          t_wait += now_s() - t0;
-          if (!rc_all && pend_slot >= 0 && deliver(&out, pend_slot, &pend_params)) rc_all = 1;
-          pend = 0;
-        }
+        t_hand += now_s() - t0;
       }
       pos += psz;
     }
-    if (pend && !rc_all) {
-      if (vp9hip_decoder_sync(dec)) rc_all = 1;
-      if (!rc_all && pend_slot >= 0 && deliver(&out, pend_slot, &pend_params)) rc_all = 1;
+    if (have_thread) {
+      pthread_mutex_lock(&g.mu);
+      while (g.has) pthread_cond_wait(&g.cv, &g.mu);
+      g.quit = 1;
+      pthread_cond_broadcast(&g.cv);
+      pthread_mutex_unlock(&g.mu);
+      pthread_join(th, NULL);
+      if (g.failed) rc_all = 1;
     }
+    if (!rc_all && gpu_flush(&g)) rc_all = 1;
     const double dt = now_s() - t_loop - out.t_hash;
     if (summary)
       fprintf(stderr, "%d decoded frames/%d showed frames in %.0f us (%.2f fps)\n", frames_in, out.frame_out, dt * 1e6,
               out.frame_out / (dt > 0 ? dt : 1));
-    if (stats)
-      fprintf(stderr, "vp9hip_dec: per frame: parse %.3f ms, pack + launch %.3f ms, wait %.3f ms, fetch %.3f ms, hash/write %.3f ms\n",
-              1e3 * t_parse / frames_in, 1e3 * t_begin / frames_in, 1e3 * t_wait / frames_in, 1e3 * out.t_fetch / frames_in,
-              1e3 * out.t_hash / frames_in);
+    if (stats && frames_in)
+      fprintf(stderr,
+              "vp9hip_dec: per frame: parse %.3f ms, hand-over wait %.3f ms | GPU thread: pack + launch %.3f ms, wait for the GPU %.3f ms, "
+              "fetch %.3f ms, hash/write %.3f ms\n",
+              1e3 * t_parse / frames_in, 1e3 * t_hand / frames_in, 1e3 * g.t_begin / frames_in, 1e3 * g.t_wait / frames_in,
+              1e3 * out.t_fetch / frames_in, 1e3 * out.t_hash / frames_in);
     for (int p = 0; p < 3; ++p)
       if (out.host[p]) vp9hip_decoder_host_free(dec, out.host[p]);
     vp9hip_decoder_sync(dec);
-    vp9hip_fe_destroy(fe[0]);
+    vp9hip_fe_destroy(fe);
+    pthread_mutex_destroy(&g.mu);
+    pthread_cond_destroy(&g.cv);
   }
   vp9hip_decoder_destroy(dec);
   free(file);

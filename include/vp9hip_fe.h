@@ -67,9 +67,9 @@ void vp9hip_fe_destroy(vp9hip_fe *fe);
 const char *vp9hip_fe_error(const vp9hip_fe *fe);
 
 /* Parses one frame (one entry of a superframe; see vp9hip_fe_split_superframe).  `out` points into the
- * front-end's arrays and stays valid until the next call.  The reference map and the probability contexts
- * advance as libvpx's do at the end of vp9_receive_compressed_data: the caller reconstructs every frame it is
- * handed, in order.  VP9HIP_OK, VP9HIP_EINVAL (corrupt / unsupported stream) or VP9HIP_ENOMEM. */
+ * front-end's arrays and stays valid for this call and the next two (three sets of output arrays in rotation).
+ * The reference map and the probability contexts advance as libvpx's do at the end of
+ * vp9_receive_compressed_data: the caller reconstructs every frame it is handed, in order.  VP9HIP_OK, VP9HIP_EINVAL (corrupt / unsupported stream) or VP9HIP_ENOMEM. */
 int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_frame *out);
 
 /* The superframe index at the end of a packet (vp9_parse_superframe_index, libvpx/vp9/vp9_dx_iface.c): sizes of
