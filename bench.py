@@ -172,6 +172,20 @@ def run_vpxdec(path, ivf, loops=1, md5=False, timeout=600):
     return [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"(\d+) decoded frames/\d+ showed frames in \d+ us \(([\d.]+) fps\)", out)]
 
 
+def run_own_dec(ivf, loops=1, md5=False, timeout=600):
+    """cuda-vp9_amd/vp9hip_dec: the decoder built only from this repository (own bitstream front-end + GPU
+    reconstruction).  md5: vpxdec's per-frame lines; else [(frames, fps)] per loop, frames fetched to the host."""
+    path = os.path.join(ROOT, "cuda-vp9_amd", "vp9hip_dec")
+    cmd = [path] + (["--md5", "-o", "img-%wx%h-%4.i420"] if md5 else ["--noblit", "--fetch", "--summary", f"--loops={loops}"]) + [ivf]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    out = r.stdout.decode(errors="replace")
+    if r.returncode:
+        raise RuntimeError(f"{' '.join(cmd)} failed ({r.returncode}): {out[-400:]}")
+    if md5:
+        return [l for l in out.splitlines() if re.match(r"^[0-9a-f]{32}  img-", l)]
+    return [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"(\d+) decoded frames/\d+ showed frames in \d+ us \(([\d.]+) fps\)", out)]
+
+
 def stream_leg():
     """The reference's vpxdec end to end on the synthesized S-1440 IVF: HIP-linked vs CPU bodies."""
     big = os.path.join(ROOT, "tests", "streams_big")
@@ -187,13 +201,20 @@ def stream_leg():
     hip_runs = run_vpxdec(hipdec, ivf, loops=4)   # first loop pays the HIP start-up; report the warm ones
     c_runs = run_vpxdec(cdec, ivf, loops=1)
     warm = hip_runs[1:] or hip_runs
+    own = {}
+    if os.path.exists(os.path.join(ROOT, "cuda-vp9_amd", "vp9hip_dec")):
+        own_runs = run_own_dec(ivf, loops=5)
+        own = {"vp9hip_dec_fps": round(sum(f for _, f in own_runs[1:]) / max(1, len(own_runs[1:])), 2),
+               "vp9hip_dec_md5_match": run_own_dec(ivf, md5=True) == want,
+               "vp9hip_dec_note": "no libvpx: the repository's own bitstream front-end (vp9hip_fe, one thread per tile column) + GPU "
+                                  "reconstruction, parsing thread and GPU thread pipelined, every shown frame fetched to the host"}
     return {"stream": "S-1440 (synthesized 2560x1440 8-bit IVF, %d frames; tests/golden/streams/make_streams.py)" % len(want),
             "md5_frames_equal": sum(a == b for a, b in zip(got, want)), "md5_frames": len(want),
             "md5_match": got == want,
             "vpxdec_hip_fps": round(sum(f for _, f in warm) / len(warm), 2), "vpxdec_hip_fps_first_loop": hip_runs[0][1],
             "vpxdec_hip_mt_fps": round(sum(f for _, f in mt_runs[1:]) / len(mt_runs[1:]), 2) if mt_runs else None,
             "vpxdec_hip_mt_md5_match": (got_mt == want) if got_mt is not None else None,
-            "vpxdec_c_fps": c_runs[0][1],
+            "vpxdec_c_fps": c_runs[0][1], **own,
             "note": "dx_time-based fps printed by vpxdec --summary (libvpx/vpxdec.c:358-363): whole decode incl. CPU entropy "
                     "stage; vpxdec_c and vpxdec_hip parse on one thread, vpxdec_hip_mt with one thread per tile column (8 here); "
                     "HIP = patched frame driver (INTEGRATION.md mode C)"}

@@ -86,7 +86,7 @@ typedef struct {
   int overrun;
 } BoolDec;
 
-static void bd_fill(BoolDec *r) {
+static inline __attribute__((always_inline)) void bd_fill(BoolDec *r) {
   int shift = 64 - 8 - (r->count + 8);
   while (shift >= 0) {
     if (r->buf < r->end) {
@@ -99,7 +99,7 @@ static void bd_fill(BoolDec *r) {
   }
 }
 
-static inline int bd_read(BoolDec *r, int prob) {
+static inline __attribute__((always_inline)) int bd_read(BoolDec *r, int prob) {
   const unsigned split = (r->range * (unsigned)prob + (256 - (unsigned)prob)) >> 8;
   if (r->count < 0) bd_fill(r);
   const uint64_t bigsplit = (uint64_t)split << 56;
@@ -193,6 +193,7 @@ struct vp9hip_fe {
   vp9hip_free_fn release;
   void *user;
   int max_threads;
+  int checksums; /* VP9HIP_FE_CHECKSUMS: per-block checksum of eobs + coefficients in reserved2 (tests/test_fe_blocks.py) */
 
   /* stream state that outlives a frame */
   ProbCtx saved[4], fc;
@@ -1482,7 +1483,7 @@ static void read_inter_frame_mode_info(TileCtx *t, int x_mis, int y_mis) { /* vp
 /* ---- coefficient tokens (decode_coefs / vp9_decode_block_tokens, vp9_detokenize.c:123-333) ------------- */
 static int read_coefs(TileCtx *t, int type, int tx, const int16_t *dq, int ctx, const int16_t *scan, const int16_t *nb, int is_inter_blk) {
   vp9hip_fe *fe = t->fe;
-  BoolDec *r = &t->bd;
+  BoolDec local = t->bd, *r = &local; /* value / range / count in registers: the byte stores below would force reloads */
   const int max_eob = 16 << (tx << 1);
   const uint8_t(*probs)[6][3] = fe->fc.coef[tx][type][is_inter_blk];
   uint32_t(*cnt)[6][4] = t->counts ? t->counts->coef[tx][type][is_inter_blk] : NULL;
@@ -1513,7 +1514,10 @@ static int read_coefs(TileCtx *t, int type, int tx, const int16_t *dq, int ctx, 
       dqv = dq[1];
       cache[scan[c]] = 0;
       ++c;
-      if (c >= max_eob) return c; /* zeros up to the end: no end-of-block token */
+      if (c >= max_eob) { /* zeros up to the end: no end-of-block token */
+        t->bd = local;
+        return c;
+      }
       ctx = (1 + cache[nb[2 * c]] + cache[nb[2 * c + 1]]) >> 1;
       band = band_tr[c];
       p = probs[band][ctx];
@@ -1570,6 +1574,7 @@ static int read_coefs(TileCtx *t, int type, int tx, const int16_t *dq, int ctx, 
     dqv = dq[1];
   }
 #undef READ_BITS
+  t->bd = local;
   return c;
 }
 
@@ -1628,7 +1633,8 @@ static int read_block_tokens(TileCtx *t) {
         uint32_t sum = 0;
         if (eob > 0) {
           const int ext = vp9hip_coeff_extent(eob, (p || tx == TX_32X32) ? 0 : tx_type, tx);
-          for (int i = 0; i < ext; ++i) sum += (uint32_t)t->scratch[i] * (uint32_t)(i + 1);
+          if (fe->checksums)
+            for (int i = 0; i < ext; ++i) sum += (uint32_t)t->scratch[i] * (uint32_t)(i + 1);
           memcpy(t->cf[p], t->scratch, sizeof(int32_t) * (size_t)ext);
           t->cf[p] += ext;
           /* the clearing rule of vp9_decodeframe.c:960-967 — what the extent is defined by */
@@ -1944,6 +1950,7 @@ int vp9hip_fe_create(vp9hip_fe **out, vp9hip_alloc_fn alloc, vp9hip_free_fn rele
   fe->user = user;
   fe->max_threads = threads;
   fe->need_resync = 1;
+  fe->checksums = getenv("VP9HIP_FE_CHECKSUMS") != NULL;
   for (int i = 0; i < 8; ++i) fe->ref_map[i] = -1;
   pthread_mutex_init(&fe->mu, NULL);
   pthread_cond_init(&fe->cv_work, NULL);

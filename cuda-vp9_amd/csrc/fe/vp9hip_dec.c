@@ -286,7 +286,7 @@ static void *gpu_main(void *arg) {
 
 int main(int argc, char **argv) {
   const char *path = NULL, *pattern = NULL;
-  int do_md5 = 0, noblit = 0, fetch = 0, summary = 0, loops = 1, threads = 0, serial = 0, stats = 0;
+  int do_md5 = 0, noblit = 0, fetch = 0, summary = 0, loops = 1, threads = 0, serial = 0, stats = 0, parse_only = 0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--md5"))
       do_md5 = 1;
@@ -300,6 +300,8 @@ int main(int argc, char **argv) {
       serial = 1;
     else if (!strcmp(argv[i], "--stats"))
       stats = 1;
+    else if (!strcmp(argv[i], "--parse-only"))
+      parse_only = 1;
     else if (!strcmp(argv[i], "--rawvideo") || !strcmp(argv[i], "--i420"))
       ;
     else if (!strncmp(argv[i], "--loops=", 8))
@@ -316,7 +318,7 @@ int main(int argc, char **argv) {
     }
   }
   if (!path) {
-    fprintf(stderr, "usage: vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] file.ivf\n");
+    fprintf(stderr, "usage: vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] [--parse-only] file.ivf\n");
     return 2;
   }
   if (!pattern && !do_md5) noblit = 1;
@@ -340,6 +342,42 @@ int main(int argc, char **argv) {
   }
   const size_t hdr = (size_t)file[6] | ((size_t)file[7] << 8);
 
+  if (parse_only) { /* the front-end alone (no GPU is touched): entropy-stage rate */
+    for (int loop = 0; loop < loops; ++loop) {
+      vp9hip_fe *fe = NULL;
+      if (vp9hip_fe_create(&fe, NULL, NULL, NULL, threads)) return 1;
+      int n = 0;
+      int64_t coefs = 0, blocks = 0;
+      const double t0 = now_s();
+      for (size_t pos = hdr; pos + 12 <= (size_t)fsz;) {
+        const size_t psz = (size_t)file[pos] | ((size_t)file[pos + 1] << 8) | ((size_t)file[pos + 2] << 16) | ((size_t)file[pos + 3] << 24);
+        pos += 12;
+        if (pos + psz > (size_t)fsz) break;
+        uint32_t sizes[8];
+        const int nf = vp9hip_fe_split_superframe(file + pos, psz, sizes);
+        size_t off = 0;
+        for (int k = 0; k < nf; ++k) {
+          vp9hip_fe_frame fr;
+          if (nf > 1 && sizes[k] == 0) continue;
+          if (vp9hip_fe_parse(fe, file + pos + off, sizes[k], &fr)) {
+            fprintf(stderr, "vp9hip_dec: frame %d: %s\n", n, vp9hip_fe_error(fe));
+            return 1;
+          }
+          off += sizes[k];
+          ++n;
+          coefs += fr.coeff_count;
+          blocks += fr.n_blocks;
+        }
+        pos += psz;
+      }
+      const double dt = now_s() - t0;
+      fprintf(stderr, "parse only: %d frames in %.0f us (%.2f fps), %.3f ms per frame, %.0f blocks and %.0f coefficients per frame\n", n, dt * 1e6,
+              n / dt, 1e3 * dt / n, (double)blocks / n, (double)coefs / n);
+      vp9hip_fe_destroy(fe);
+    }
+    free(file);
+    return 0;
+  }
   vp9hip_decoder *dec = NULL;
   if (vp9hip_decoder_create(0, &dec)) {
     fprintf(stderr, "vp9hip_dec: no HIP device / decoder (%s)\n", dec ? vp9hip_decoder_error(dec) : "create failed");

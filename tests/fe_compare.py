@@ -61,7 +61,9 @@ def parse_stream(hip, path, threads=1):
     lib.vp9hip_fe_destroy.argtypes = [ctypes.c_void_p]
     lib.vp9hip_fe_split_superframe.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32 * 8)]
     fe = ctypes.c_void_p()
+    os.environ["VP9HIP_FE_CHECKSUMS"] = "1"  # read at creation: per-block checksums over eobs + coefficients
     assert lib.vp9hip_fe_create(ctypes.byref(fe), None, None, None, threads) == 0
+    del os.environ["VP9HIP_FE_CHECKSUMS"]
     frames = []
     try:
         for pkt in ivf_frames(path):

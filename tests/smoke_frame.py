@@ -49,6 +49,16 @@ def run(verbose=False):
             raise AssertionError("smoke: vpxdec_hip_mt on s704_8.ivf: per-frame MD5s differ from the CPU path's")
         if verbose:
             print(f"smoke ok: s704_8.ivf through vpxdec -> decode_tiles -> wrap_cuda_* -> HIP, {len(want)} frames MD5-equal")
+    # and the same stream through the decoder built only from this repository (own front-end + GPU reconstruction)
+    own = os.path.join(ROOT, "cuda-vp9_amd", "vp9hip_dec")
+    if os.path.exists(own):
+        out = subprocess.run([own, "--md5", "-o", "img-%wx%h-%4.i420", ivf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        got_md5 = [l for l in out.stdout.decode(errors="replace").splitlines() if re.match(r"^[0-9a-f]{32}  img-", l)]
+        want = [l.rstrip("\n") for l in open(ivf[:-4] + ".md5") if l.strip()]
+        if out.returncode or got_md5 != want:
+            raise AssertionError("smoke: vp9hip_dec on s704_8.ivf: per-frame MD5s differ from the reference CPU path's")
+        if verbose:
+            print(f"smoke ok: s704_8.ivf through vp9hip_dec (vp9hip_fe -> vp9hip_decoder), {len(want)} frames MD5-equal")
 
 
 if __name__ == "__main__":

@@ -29,6 +29,11 @@ def main():
             warm = runs[1:] or runs
             row[name + "_fps"] = round(sum(f for _, f in warm) / len(warm), 1)
             row[name + "_fps_runs"] = [f for _, f in runs]
+        if os.path.exists(os.path.join(ROOT, "cuda-vp9_amd", "vp9hip_dec")):
+            row["vp9hip_dec_md5_equal"] = bench.run_own_dec(ivf, md5=True) == want
+            runs = bench.run_own_dec(ivf, loops=5)
+            row["vp9hip_dec_fps"] = round(sum(f for _, f in runs[1:]) / max(1, len(runs[1:])), 1)
+            row["vp9hip_dec_fps_runs"] = [f for _, f in runs]
         out[s] = row
         print(s, json.dumps(row), file=sys.stderr, flush=True)
     print(json.dumps(out))
