@@ -45,6 +45,21 @@ STREAMS = {
     "s704_10": (704, 576, 6, 710, 6, 2, 10, "420", 0.4, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=2", "--cq-level=30", "--tile-columns=1", "--lag-in-frames=0", "--passes=1"], False),
     # 4:4:4 (profile 1): chroma planes as large as luma, loop-filtered with the luma masks (LF_PATH_444)
     "s352_444": (352, 288, 6, 444, 3, 2, 8, "444", 0.4, 0, ["--profile=1", "--cpu-used=2", "--cq-level=30", "--lag-in-frames=0", "--passes=1"], False),
+    # syntax the streams above do not reach (all 352x288, a few frames):
+    # segmentation: variance AQ (per-segment quantiser, segment map coded in every frame)
+    "s352_aq1": (352, 288, 6, 3521, 3, 2, 8, "420", 0.4, 0, ["--cpu-used=2", "--cq-level=30", "--aq-mode=1", "--lag-in-frames=0", "--passes=1"], False),
+    # segmentation with temporal prediction of the map: cyclic refresh (real-time, CBR)
+    "s352_aq3": (352, 288, 8, 3523, 2, 1, 8, "420", 0.3, 0, ["--rt", "--cpu-used=5", "--end-usage=cbr", "--target-bitrate=300", "--aq-mode=3", "--lag-in-frames=0", "--passes=1", "--error-resilient=0"], False),
+    # error-resilient: every frame resets its contexts, no backward adaptation, no previous-frame vectors
+    "s352_er": (352, 288, 6, 3524, 4, 2, 8, "420", 0.4, 0, ["--cpu-used=2", "--cq-level=30", "--error-resilient=1", "--lag-in-frames=0", "--passes=1"], False),
+    # frame-parallel mode: forward probability updates only
+    "s352_fp": (352, 288, 6, 3525, 4, 2, 8, "420", 0.4, 0, ["--cpu-used=2", "--cq-level=30", "--frame-parallel=1", "--lag-in-frames=0", "--passes=1"], False),
+    # lossless: Walsh-Hadamard 4x4 only, base_qindex 0
+    "s352_ll": (352, 288, 3, 3526, 2, 1, 8, "420", 0.0, 0, ["--cpu-used=2", "--lossless=1", "--lag-in-frames=0", "--passes=1"], False),
+    # 12-bit profile 2: 18-bit coefficient category
+    "s352_12": (320, 256, 4, 3527, 3, 2, 12, "420", 0.4, 0, ["--profile=2", "--bit-depth=12", "--input-bit-depth=12", "--cpu-used=2", "--cq-level=24", "--lag-in-frames=0", "--passes=1"], False),
+    # four tile rows and two tile columns
+    "s352_tr": (352, 288, 5, 3528, 3, 2, 8, "420", 0.4, 0, ["--cpu-used=2", "--cq-level=30", "--tile-columns=1", "--tile-rows=2", "--lag-in-frames=0", "--passes=1"], False),
     # BASELINE.json-sized streams (SURVEY §8d / BASELINE.md §2)
     "S-1440": (2560, 1440, 60, 1440, 5, 3, 8, "420", 0.1, 0, ["--cpu-used=2", "--cq-level=24", "--tile-columns=3", "--lag-in-frames=0", "--passes=1"], True),
     "S-2160": (3840, 2160, 30, 2160, 23, -17, 8, "420", 0.0, 8, ["--cpu-used=4", "--cq-level=32", "--tile-columns=4", "--lag-in-frames=0", "--passes=1"], True),

@@ -34,7 +34,8 @@ def check(d, name, *opts):
     assert not bad, f"{name}: frames {bad[:8]} differ, first: {got[bad[0]]} != {want[bad[0]]}"
 
 
-@pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444"])
+@pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444", "s352_aq1", "s352_aq3", "s352_er", "s352_fp", "s352_ll",
+                                  "s352_12", "s352_tr"])
 def test_standalone_decoder_md5(name):
     assert os.path.exists(DEC), "cuda-vp9_amd/vp9hip_dec not built (make -C cuda-vp9_amd)"
     check(SMALL, name)

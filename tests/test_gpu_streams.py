@@ -55,14 +55,16 @@ def check(decoder, directory, name):
     assert not bad, f"{name}: frames {bad[:8]} differ, e.g. {got[bad[0]]} != {want[bad[0]]}"
 
 
-@pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444"])
+@pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444", "s352_aq1", "s352_aq3", "s352_er", "s352_fp", "s352_ll", "s352_12",
+                                  "s352_tr"])
 def test_stream_md5_patched_driver(name):
     check(HIP, SMALL, name)
 
 
-@pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444"])
+@pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444", "s352_aq1", "s352_aq3", "s352_er", "s352_fp", "s352_ll", "s352_12",
+                                  "s352_tr"])
 def test_stream_md5_tile_parallel_entropy_stage(name):
-    # s704_8 / s704_10 have two tile columns; the others take the driver's serial loop
+    # every stream goes through the tile-column threads (one column: one thread) with compact coefficient slots
     check(HIP_MT, SMALL, name)
 
 
