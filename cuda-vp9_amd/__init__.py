@@ -174,6 +174,78 @@ def _arr(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
+class FeFrame(ctypes.Structure):
+    """vp9hip_fe_frame (include/vp9hip_fe.h)."""
+    _fields_ = [("show_existing", ctypes.c_int32), ("show_slot", ctypes.c_int32), ("show_frame", ctypes.c_int32),
+                ("key_frame", ctypes.c_int32), ("intra_only", ctypes.c_int32), ("error_resilient", ctypes.c_int32),
+                ("new_slot", ctypes.c_int32), ("ref_slot", ctypes.c_int32 * 3), ("refresh_flags", ctypes.c_int32),
+                ("filter_level", ctypes.c_int32), ("sharpness", ctypes.c_int32), ("lf_thresh", LfThresh),
+                ("params", FrameParams), ("blocks", ctypes.c_void_p), ("n_blocks", ctypes.c_int32),
+                ("layout", CoeffLayout), ("dqcoeff", ctypes.c_void_p * 3), ("coeff_count", ctypes.c_int64),
+                ("tile_cols", ctypes.c_int32), ("tile_rows", ctypes.c_int32)]
+
+
+def ivf_packets(path):
+    """The packets of an IVF file (libvpx/ivfdec.c: 32-byte file header, 12-byte frame headers)."""
+    data = open(path, "rb").read()
+    if data[:4] != b"DKIF":
+        raise Vp9HipError(f"{path} is not an IVF file")
+    pos = int.from_bytes(data[6:8], "little")
+    while pos + 12 <= len(data):
+        n = int.from_bytes(data[pos:pos + 4], "little")
+        pos += 12
+        yield data[pos:pos + n]
+        pos += n
+
+
+class FrontEnd:
+    """vp9hip_fe (include/vp9hip_fe.h): the bitstream front-end, CPU only.  decoder: a Decoder whose page-locked
+    memory the coefficient arrays come from (None: ordinary memory)."""
+
+    def __init__(self, threads=0, decoder=None):
+        L = lib()
+        vp = ctypes.c_void_p
+        L.vp9hip_fe_create.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ctypes.c_int]
+        L.vp9hip_fe_parse.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(FeFrame)]
+        L.vp9hip_fe_error.restype = ctypes.c_char_p
+        L.vp9hip_fe_error.argtypes = [vp]
+        L.vp9hip_fe_destroy.argtypes = [vp]
+        L.vp9hip_fe_destroy.restype = None
+        L.vp9hip_fe_split_superframe.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32 * 8)]
+        self.handle = vp()
+        self._cb = None
+        alloc = release = user = None
+        if decoder is not None:
+            A = ctypes.CFUNCTYPE(vp, vp, ctypes.c_size_t)
+            R = ctypes.CFUNCTYPE(None, vp, vp)
+            self._cb = (A(lambda u, n: L.vp9hip_decoder_host_alloc(decoder.handle, n)),
+                        R(lambda u, p: L.vp9hip_decoder_host_free(decoder.handle, p)))
+            alloc, release = ctypes.cast(self._cb[0], vp), ctypes.cast(self._cb[1], vp)
+        if L.vp9hip_fe_create(ctypes.byref(self.handle), alloc, release, user, threads) != 0:
+            raise Vp9HipError("vp9hip_fe_create failed")
+
+    def frames_of(self, packet):
+        """The frames a packet holds (superframe index), each as bytes."""
+        sizes = (ctypes.c_uint32 * 8)()
+        n = lib().vp9hip_fe_split_superframe(packet, len(packet), ctypes.byref(sizes))
+        off = 0
+        for k in range(n):
+            if not (n > 1 and sizes[k] == 0):
+                yield packet[off:off + sizes[k]]
+            off += sizes[k]
+
+    def parse(self, frame_bytes):
+        fr = FeFrame()
+        if lib().vp9hip_fe_parse(self.handle, frame_bytes, len(frame_bytes), ctypes.byref(fr)) != 0:
+            raise Vp9HipError("vp9hip_fe_parse: " + lib().vp9hip_fe_error(self.handle).decode())
+        return fr
+
+    def close(self):
+        if self.handle:
+            lib().vp9hip_fe_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
 class Decoder:
     """vp9hip_decoder (include/vp9hip_decoder.h): frame pool + transfers + phase sequencing."""
 
@@ -264,6 +336,22 @@ class Decoder:
                                                        ctypes.byref(cl) if cl is not None else None,
                                                        ctypes.byref(dq) if dq is not None else None, int(bool(persistent))))
         return lib().vp9hip_decoder_current_set(self.handle)
+
+    def begin_parsed(self, fr, persistent=True):
+        """A frame as the front-end parsed it (FeFrame): slot, pack, upload.  Returns the ring set."""
+        P = fr.params
+        self.check(lib().vp9hip_decoder_alloc_slot(self.handle, fr.new_slot, P.width, P.height, P.ss_x, P.bit_depth, P.hbd, 0))
+        dq = (ctypes.c_void_p * 3)(*fr.dqcoeff)
+        self.check(lib().vp9hip_decoder_begin_frame_ex(self.handle, ctypes.byref(fr.params), fr.blocks, fr.n_blocks,
+                                                       ctypes.byref(fr.layout), ctypes.byref(dq), int(bool(persistent))))
+        return lib().vp9hip_decoder_current_set(self.handle)
+
+    def run_parsed(self, fr):
+        """All phases of a parsed frame (inter unless it is an intra frame, intra, loop filter when the frame has one)."""
+        phases = PHASE_INTRA | (0 if (fr.key_frame or fr.intra_only) else PHASE_INTER) | (PHASE_LF if fr.filter_level else 0)
+        rs = (ctypes.c_int * 3)(*fr.ref_slot)
+        self.check(lib().vp9hip_decoder_run(self.handle, phases, ctypes.byref(rs), fr.new_slot, None,
+                                            ctypes.addressof(fr.lf_thresh) if fr.filter_level else None))
 
     def set_timing(self, on):
         self.check(lib().vp9hip_decoder_set_timing(self.handle, int(bool(on))))

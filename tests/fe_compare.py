@@ -20,70 +20,27 @@ REC = np.dtype([("mi_row", "<i2"), ("mi_col", "<i2"), ("sb_type", "u1"), ("tx_si
 assert REC.itemsize == 64
 
 
-class FeFrame(ctypes.Structure):
-    pass
-
-
-def _fe_frame_struct(hip):
-    class LfThresh(ctypes.Structure):
-        _fields_ = [("mblim", ctypes.c_uint8 * 64), ("lim", ctypes.c_uint8 * 64), ("hev_thr", ctypes.c_uint8 * 64)]
-
-    class F(ctypes.Structure):
-        _fields_ = [("show_existing", ctypes.c_int32), ("show_slot", ctypes.c_int32), ("show_frame", ctypes.c_int32),
-                    ("key_frame", ctypes.c_int32), ("intra_only", ctypes.c_int32), ("error_resilient", ctypes.c_int32),
-                    ("new_slot", ctypes.c_int32), ("ref_slot", ctypes.c_int32 * 3), ("refresh_flags", ctypes.c_int32),
-                    ("filter_level", ctypes.c_int32), ("sharpness", ctypes.c_int32), ("lf_thresh", LfThresh),
-                    ("params", hip.FrameParams), ("blocks", ctypes.c_void_p), ("n_blocks", ctypes.c_int32),
-                    ("layout", hip.CoeffLayout), ("dqcoeff", ctypes.c_void_p * 3), ("coeff_count", ctypes.c_int64),
-                    ("tile_cols", ctypes.c_int32), ("tile_rows", ctypes.c_int32)]
-    return F
-
-
 def ivf_frames(path):
-    data = open(path, "rb").read()
-    assert data[:4] == b"DKIF"
-    pos = int.from_bytes(data[6:8], "little")
-    while pos + 12 <= len(data):
-        n = int.from_bytes(data[pos:pos + 4], "little")
-        pos += 12
-        yield data[pos:pos + n]
-        pos += n
+    import __graft_entry__ as g
+    return g.load_pkg().ivf_packets(path)
 
 
 def parse_stream(hip, path, threads=1):
     """Every decoded frame's block records as the product's front-end parses them."""
-    lib = hip.lib()
-    F = _fe_frame_struct(hip)
-    lib.vp9hip_fe_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-    lib.vp9hip_fe_parse.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(F)]
-    lib.vp9hip_fe_error.restype = ctypes.c_char_p
-    lib.vp9hip_fe_error.argtypes = [ctypes.c_void_p]
-    lib.vp9hip_fe_destroy.argtypes = [ctypes.c_void_p]
-    lib.vp9hip_fe_split_superframe.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32 * 8)]
-    fe = ctypes.c_void_p()
     os.environ["VP9HIP_FE_CHECKSUMS"] = "1"  # read at creation: per-block checksums over eobs + coefficients
-    assert lib.vp9hip_fe_create(ctypes.byref(fe), None, None, None, threads) == 0
+    fe = hip.FrontEnd(threads=threads)
     del os.environ["VP9HIP_FE_CHECKSUMS"]
     frames = []
     try:
-        for pkt in ivf_frames(path):
-            sizes = (ctypes.c_uint32 * 8)()
-            nf = lib.vp9hip_fe_split_superframe(pkt, len(pkt), ctypes.byref(sizes))
-            off = 0
-            for k in range(nf):
-                if nf > 1 and sizes[k] == 0:
-                    continue
-                fr = F()
-                rc = lib.vp9hip_fe_parse(fe, pkt[off:off + sizes[k]], sizes[k], ctypes.byref(fr))
-                off += sizes[k]
-                if rc:
-                    raise RuntimeError(f"frame {len(frames)}: vp9hip_fe_parse: {lib.vp9hip_fe_error(fe).decode()}")
+        for pkt in hip.ivf_packets(path):
+            for data in fe.frames_of(pkt):
+                fr = fe.parse(data)
                 if fr.show_existing:
                     continue
                 buf = (ctypes.c_char * (64 * fr.n_blocks)).from_address(fr.blocks)
                 frames.append(np.frombuffer(bytes(buf), REC).copy())
     finally:
-        lib.vp9hip_fe_destroy(fe)
+        fe.close()
     return frames
 
 
