@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "vp9hip_fe.h"
 
@@ -193,6 +194,9 @@ struct vp9hip_fe {
   vp9hip_free_fn release;
   void *user;
   int max_threads;
+  int trace;     /* VP9HIP_FE_TRACE: where a frame's parse time goes, printed when the front-end is destroyed */
+  double tr_total, tr_head, tr_tiles, tr_tile_sum, tr_tile_max, tr_tail;
+  int tr_frames;
   int checksums; /* VP9HIP_FE_CHECKSUMS: per-block checksum of eobs + coefficients in reserved2 (tests/test_fe_blocks.py) */
 
   /* stream state that outlives a frame */
@@ -759,6 +763,7 @@ typedef struct TileCtx {
 } TileCtx;
 
 struct TileJob {
+  double seconds; /* VP9HIP_FE_TRACE */
   TileCtx tc;
   TileBuf buf[4]; /* per tile row */
   Counts counts;
@@ -1767,8 +1772,15 @@ static int tile_offset(int idx, int mis, int log2) { /* get_tile_offset, vp9_til
 }
 
 /* one tile column, its tile rows top to bottom (they share the above context) */
+static double fe_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static void run_tile_job(vp9hip_fe *fe, TileJob *job) {
   TileCtx *t = &job->tc;
+  const double t_start = fe->trace ? fe_now() : 0.0;
   const int tile_rows = 1 << fe->h.log2_tile_rows;
   for (int tr = 0; tr < tile_rows && !t->corrupt; ++tr) {
     if (bd_init(&t->bd, job->buf[tr].data, job->buf[tr].size)) {
@@ -1789,6 +1801,7 @@ static void run_tile_job(vp9hip_fe *fe, TileJob *job) {
   }
   job->n_blocks = (int)(t->blk - t->seg_first);
   for (int p = 0; p < 3; ++p) job->cf_used[p] = t->cf[p] - t->cf_base[p];
+  if (fe->trace) job->seconds = fe_now() - t_start;
 }
 
 /* ---- thread pool: tile columns of a frame in parallel -------------------------------------------------- */
@@ -1951,6 +1964,7 @@ int vp9hip_fe_create(vp9hip_fe **out, vp9hip_alloc_fn alloc, vp9hip_free_fn rele
   fe->max_threads = threads;
   fe->need_resync = 1;
   fe->checksums = getenv("VP9HIP_FE_CHECKSUMS") != NULL;
+  fe->trace = getenv("VP9HIP_FE_TRACE") != NULL;
   for (int i = 0; i < 8; ++i) fe->ref_map[i] = -1;
   pthread_mutex_init(&fe->mu, NULL);
   pthread_cond_init(&fe->cv_work, NULL);
@@ -1987,6 +2001,12 @@ static void use_set(vp9hip_fe *fe, int k) {
 
 void vp9hip_fe_destroy(vp9hip_fe *fe) {
   if (!fe) return;
+  if (fe->trace && fe->tr_frames)
+    fprintf(stderr,
+            "vp9hip_fe: %d frames; per frame %.3f ms: headers + set-up %.3f, tile columns %.3f (longest column %.3f, all columns "
+            "together %.3f), merge + adaptation + state %.3f\n",
+            fe->tr_frames, 1e3 * fe->tr_total / fe->tr_frames, 1e3 * fe->tr_head / fe->tr_frames, 1e3 * fe->tr_tiles / fe->tr_frames,
+            1e3 * fe->tr_tile_max / fe->tr_frames, 1e3 * fe->tr_tile_sum / fe->tr_frames, 1e3 * fe->tr_tail / fe->tr_frames);
   pthread_mutex_lock(&fe->mu);
   fe->pool_stop = 1;
   pthread_cond_broadcast(&fe->cv_work);
@@ -2113,6 +2133,7 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
   if (!fe || !out) return VP9HIP_EINVAL;
   if (!data || !size) FE_FAIL(fe, "empty frame");
   memset(out, 0, sizeof(*out));
+  const double tr0 = fe->trace ? fe_now() : 0.0;
   BitRd rb = { data, size * 8, 0, 0 };
   int rc = read_uncompressed_header(fe, &rb, out);
   if (rc) return rc;
@@ -2214,7 +2235,9 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
       t->cf[p] = t->cf_base[p] = fe->coef[p] + jobs[c].cf_start[p];
     }
   }
+  const double tr1 = fe->trace ? fe_now() : 0.0;
   run_jobs(fe, tile_cols);
+  const double tr2 = fe->trace ? fe_now() : 0.0;
   int corrupt = 0, total = 0;
   for (int c = 0; c < tile_cols; ++c) {
     corrupt |= jobs[c].tc.corrupt;
@@ -2337,5 +2360,20 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
     }
   L->regions = fe->sets[fe->set_idx].regions;
   L->n_regions = nr;
+  if (fe->trace) {
+    const double tr3 = fe_now();
+    double mx = 0, sum = 0;
+    for (int c = 0; c < tile_cols; ++c) {
+      sum += jobs[c].seconds;
+      if (jobs[c].seconds > mx) mx = jobs[c].seconds;
+    }
+    fe->tr_total += tr3 - tr0;
+    fe->tr_head += tr1 - tr0;
+    fe->tr_tiles += tr2 - tr1;
+    fe->tr_tail += tr3 - tr2;
+    fe->tr_tile_sum += sum;
+    fe->tr_tile_max += mx;
+    ++fe->tr_frames;
+  }
   return VP9HIP_OK;
 }
