@@ -47,3 +47,41 @@ def test_standalone_decoder_md5_baseline_sized(name):
     if not os.path.exists(os.path.join(BIG, name + ".ivf")):
         pytest.skip("tests/streams_big not generated (make_streams.py --big)")
     check(BIG, name)
+
+
+def test_standalone_decoder_writes_the_frames_it_hashes(tmp_path):
+    """-o without --md5: one raw file per shown frame (vpxdec's multi-file mode); the files' MD5s are the golden lines."""
+    import hashlib
+    ivf = os.path.join(SMALL, "s352_arf.ivf")  # hidden frames and a show-existing frame: the numbering follows shown frames
+    pattern = str(tmp_path / "img-%wx%h-%4.i420")
+    r = subprocess.run([DEC, "-o", pattern, ivf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-500:]
+    want = golden(os.path.join(SMALL, "s352_arf.md5"))
+    for line in want:
+        digest, name = line.split()
+        data = open(tmp_path / name, "rb").read()
+        assert len(data) == 352 * 288 * 3 // 2
+        assert hashlib.md5(data).hexdigest() == digest, name
+    assert len(list(tmp_path.iterdir())) == len(want)
+
+
+def test_standalone_decoder_refuses_a_damaged_stream(tmp_path):
+    """A stream cut in the middle of a frame ends with an error message and a non-zero exit code, not with a fault."""
+    data = open(os.path.join(SMALL, "s704_8.ivf"), "rb").read()
+    # keep the IVF framing intact but overwrite the second half of the third packet's payload
+    pos, k = 32, 0
+    while k < 2:
+        pos += 12 + int.from_bytes(data[pos:pos + 4], "little")
+        k += 1
+    n = int.from_bytes(data[pos:pos + 4], "little")
+    bad = bytearray(data)
+    for i in range(pos + 12 + n // 2, pos + 12 + n):
+        bad[i] = (i * 37) & 0xff
+    p = tmp_path / "bad.ivf"
+    p.write_bytes(bytes(bad))
+    r = subprocess.run([DEC, "--md5", "-o", "img-%wx%h-%4.i420", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    lines = [l for l in r.stdout.decode().splitlines() if re.match(r"^[0-9a-f]{32}  img-", l)]
+    want = golden(os.path.join(SMALL, "s704_8.md5"))
+    assert lines[:2] == want[:2]  # the frames before the damage are right
+    # the damaged frame either fails to parse (error exit) or decodes to something else; it never takes the process down
+    assert r.returncode in (0, 1) and (r.returncode == 1 or lines[2:3] != want[2:3])
