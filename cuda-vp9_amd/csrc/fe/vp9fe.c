@@ -89,6 +89,16 @@ typedef struct {
 
 static inline __attribute__((always_inline)) void bd_fill(BoolDec *r) {
   int shift = 64 - 8 - (r->count + 8);
+  if (r->end - r->buf >= 8) { /* whole bytes that fit, in one load */
+    uint64_t be;
+    memcpy(&be, r->buf, 8);
+    be = __builtin_bswap64(be);
+    const int bits = (shift & ~7) + 8;
+    r->value |= (be >> (64 - bits)) << (shift & 7);
+    r->count += bits;
+    r->buf += bits >> 3;
+    return;
+  }
   while (shift >= 0) {
     if (r->buf < r->end) {
       r->value |= (uint64_t)*r->buf++ << shift;
