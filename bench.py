@@ -172,11 +172,11 @@ def run_vpxdec(path, ivf, loops=1, md5=False, timeout=600):
     return [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"(\d+) decoded frames/\d+ showed frames in \d+ us \(([\d.]+) fps\)", out)]
 
 
-def run_own_dec(ivf, loops=1, md5=False, timeout=600):
+def run_own_dec(ivf, loops=1, md5=False, timeout=600, device=0):
     """cuda-vp9_amd/vp9hip_dec: the decoder built only from this repository (own bitstream front-end + GPU
     reconstruction).  md5: vpxdec's per-frame lines; else [(frames, fps)] per loop, frames fetched to the host."""
     path = os.path.join(ROOT, "cuda-vp9_amd", "vp9hip_dec")
-    cmd = [path] + (["--md5", "-o", "img-%wx%h-%4.i420"] if md5 else ["--noblit", "--fetch", "--summary", f"--loops={loops}"]) + [ivf]
+    cmd = [path, f"--device={device}"] + (["--md5", "-o", "img-%wx%h-%4.i420"] if md5 else ["--noblit", "--fetch", "--summary", f"--loops={loops}"]) + [ivf]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
     out = r.stdout.decode(errors="replace")
     if r.returncode:
@@ -478,6 +478,25 @@ def main():
         for d in decs:
             d.close()
 
+    # ---- extra leg (N > 1): the north star's batch — one real stream per GPU through the stand-alone decoder ------
+    streams_per_gpu = None
+    ivf_big = os.path.join(ROOT, "tests", "streams_big", "S-1440.ivf")
+    have_own = os.path.exists(ivf_big) and os.path.exists(os.path.join(ROOT, "cuda-vp9_amd", "vp9hip_dec"))
+    if world > 1 and not args.no_stream and not args.dry_run:
+        fps_mine, frames_mine = 0.0, 0
+        if have_own:
+            try:
+                runs = run_own_dec(ivf_big, loops=5, device=local_rank)
+                warm = runs[1:] or runs
+                fps_mine, frames_mine = sum(f for _, f in warm) / len(warm), warm[0][0]
+            except (RuntimeError, subprocess.TimeoutExpired, OSError):
+                fps_mine = 0.0
+        # sum of the ranks' rates: the streams are independent, every rank decodes its own copy on its own GPU
+        tot, _, _ = batch.reduce_stats(dist, fps_mine, 0.0, 1.0, device=dev)
+        streams_per_gpu = {"frames_per_s_all_gpus": round(float(tot), 1), "streams": world, "frames_per_stream": frames_mine,
+                           "note": "S-1440 (real bitstream) through cuda-vp9_amd/vp9hip_dec on every GPU at once, one stream per GPU, "
+                                   "frames fetched to the host; sum of the ranks' warm-loop rates"}
+
     # stats reduce: total frames (sum) and slowest rank (max) — the only collective in the harness
     frames_total, _, t_max = batch.reduce_stats(dist, args.steps, 0.0, elapsed, device=dev)
     pipe_total, _, t_pipe_max = batch.reduce_stats(dist, n_pipe, 0.0, t_pipe, device=dev)
@@ -534,7 +553,7 @@ def main():
                                 "host_pack_threads": int(os.environ["VP9HIP_PACK_THREADS"]),
                                 "note": "every step packs the frame on the host and uploads lists + coefficients from "
                                         "page-locked memory (ring of 4 list sets) while the previous frame's kernels run"},
-            "stream": stream, "multi_stream": multi,
+            "stream": stream, "multi_stream": multi, "stream_per_gpu": streams_per_gpu,
         }
         print(json.dumps(out))
     dec.close()

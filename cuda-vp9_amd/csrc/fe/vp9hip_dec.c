@@ -3,7 +3,8 @@
  * CPU) -> vp9hip_decoder (reconstruction on the GPU: inter prediction, inverse transforms, intra prediction,
  * loop filter) -> frames / per-frame MD5s in vpxdec's format.  No libvpx on either side.
  *
- *   vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] file.ivf
+ *   vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--device=N] [--serial] [--stats]
+ *              [--parse-only] file.ivf
  *
  * --md5 with -o 'img-%wx%h-%4.i420' prints what `vpxdec --rawvideo --md5 -o img-%wx%h-%4.i420` prints (vpxdec.c:285-302,
  * 1036-1042): one MD5 per shown frame over its visible samples (2 bytes each above 8 bits).  Without --md5 and
@@ -286,7 +287,7 @@ static void *gpu_main(void *arg) {
 
 int main(int argc, char **argv) {
   const char *path = NULL, *pattern = NULL;
-  int do_md5 = 0, noblit = 0, fetch = 0, summary = 0, loops = 1, threads = 0, serial = 0, stats = 0, parse_only = 0;
+  int do_md5 = 0, noblit = 0, fetch = 0, summary = 0, loops = 1, threads = 0, serial = 0, stats = 0, parse_only = 0, device = 0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--md5"))
       do_md5 = 1;
@@ -308,6 +309,8 @@ int main(int argc, char **argv) {
       loops = atoi(argv[i] + 8);
     else if (!strncmp(argv[i], "--threads=", 10))
       threads = atoi(argv[i] + 10);
+    else if (!strncmp(argv[i], "--device=", 9))
+      device = atoi(argv[i] + 9);
     else if (!strcmp(argv[i], "-o") && i + 1 < argc)
       pattern = argv[++i];
     else if (argv[i][0] != '-')
@@ -318,7 +321,7 @@ int main(int argc, char **argv) {
     }
   }
   if (!path) {
-    fprintf(stderr, "usage: vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--serial] [--stats] [--parse-only] file.ivf\n");
+    fprintf(stderr, "usage: vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--device=N] [--serial] [--stats] [--parse-only] file.ivf\n");
     return 2;
   }
   if (!pattern && !do_md5) noblit = 1;
@@ -379,7 +382,7 @@ int main(int argc, char **argv) {
     return 0;
   }
   vp9hip_decoder *dec = NULL;
-  if (vp9hip_decoder_create(0, &dec)) {
+  if (vp9hip_decoder_create(device, &dec)) {
     fprintf(stderr, "vp9hip_dec: no HIP device / decoder (%s)\n", dec ? vp9hip_decoder_error(dec) : "create failed");
     return 1;
   }
