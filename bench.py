@@ -485,12 +485,13 @@ def main():
     if world > 1 and not args.no_stream and not args.dry_run:
         fps_mine, frames_mine = 0.0, 0
         if have_own:
-            try:
-                runs = run_own_dec(ivf_big, loops=5, device=local_rank)
+            try:  # whatever happens here, every rank reaches the collective below
+                runs = run_own_dec(ivf_big, loops=5, device=local_rank, timeout=300)
                 warm = runs[1:] or runs
-                fps_mine, frames_mine = sum(f for _, f in warm) / len(warm), warm[0][0]
-            except (RuntimeError, subprocess.TimeoutExpired, OSError):
-                fps_mine = 0.0
+                if warm:
+                    fps_mine, frames_mine = sum(f for _, f in warm) / len(warm), warm[0][0]
+            except Exception:  # noqa: BLE001
+                fps_mine, frames_mine = 0.0, 0
         # sum of the ranks' rates: the streams are independent, every rank decodes its own copy on its own GPU
         tot, _, _ = batch.reduce_stats(dist, fps_mine, 0.0, 1.0, device=dev)
         streams_per_gpu = {"frames_per_s_all_gpus": round(float(tot), 1), "streams": world, "frames_per_stream": frames_mine,
