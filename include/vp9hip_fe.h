@@ -59,6 +59,10 @@ typedef struct vp9hip_fe_frame {
   int32_t tile_cols, tile_rows;
 } vp9hip_fe_frame;
 
+/* Environment (read by vp9hip_fe_create): VP9HIP_FE_TRACE — print where a frame's parse time went when the front-end
+ * is destroyed; VP9HIP_FE_CHECKSUMS — a checksum over every block's eobs and coefficients in vp9hip_block.reserved2
+ * (reserved[0] always holds the block's segment id, reserved[2] its skip flag as parsed): tests/test_fe_blocks.py. */
+
 /* alloc / release (both or neither): where the coefficient arrays come from — the frame driver's page-locked
  * memory (vp9hip_decoder_host_alloc) lets them travel asynchronously.  threads: entropy threads (one tile column
  * each at most); <= 0: number of tile columns, capped at 16. */
