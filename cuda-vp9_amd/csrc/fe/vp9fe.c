@@ -934,6 +934,43 @@ static int ctx_single_ref_p2(const TileCtx *t) { /* vp9_pred_common.c:232 */
 #undef USES_GOLD
 }
 
+/* Test hook (include/vp9hip_fe.h): the eight neighbour contexts of one (above, left) pair */
+void vp9hip_fe_debug_contexts(const vp9hip_block *above, const vp9hip_block *left, const int32_t sign_bias[3], int max_tx,
+                              int32_t out[8]) {
+  vp9hip_fe *fe = (vp9hip_fe *)calloc(1, sizeof(*fe));
+  TileCtx t;
+  if (!fe) return;
+  memset(&t, 0, sizeof(t));
+  t.fe = fe;
+  t.above = above;
+  t.left = left;
+  for (int i = 0; i < 3; ++i) fe->ref_sign_bias[1 + i] = sign_bias[i];
+  /* vp9_setup_compound_reference_mode, as read_compressed_header does it */
+  FrameHdr *h = &fe->h;
+  if (fe->ref_sign_bias[LAST_FRAME] == fe->ref_sign_bias[GOLDEN_FRAME]) {
+    h->comp_fixed_ref = ALTREF_FRAME;
+    h->comp_var_ref[0] = LAST_FRAME;
+    h->comp_var_ref[1] = GOLDEN_FRAME;
+  } else if (fe->ref_sign_bias[LAST_FRAME] == fe->ref_sign_bias[ALTREF_FRAME]) {
+    h->comp_fixed_ref = GOLDEN_FRAME;
+    h->comp_var_ref[0] = LAST_FRAME;
+    h->comp_var_ref[1] = ALTREF_FRAME;
+  } else {
+    h->comp_fixed_ref = LAST_FRAME;
+    h->comp_var_ref[0] = GOLDEN_FRAME;
+    h->comp_var_ref[1] = ALTREF_FRAME;
+  }
+  out[0] = ctx_skip(&t);
+  out[1] = ctx_intra_inter(&t);
+  out[2] = ctx_interp(&t);
+  out[3] = ctx_tx_size(&t, max_tx);
+  out[4] = ctx_reference_mode(&t);
+  out[5] = ctx_comp_ref(&t);
+  out[6] = ctx_single_ref_p1(&t);
+  out[7] = ctx_single_ref_p2(&t);
+  free(fe);
+}
+
 /* ---- segment ids (vp9_decodemv.c:93-176) ---------------------------------------------------------------- */
 static void seg_cells_set(uint8_t *map, int cols, int mi_row, int mi_col, int x_mis, int y_mis, int id) {
   for (int y = 0; y < y_mis; ++y) memset(map + (size_t)(mi_row + y) * cols + mi_col, id, (size_t)x_mis);

@@ -80,6 +80,13 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
  * the frames the packet holds.  Returns the number of frames (1 with sizes[0] = size when there is no index). */
 int vp9hip_fe_split_superframe(const uint8_t *data, size_t size, uint32_t sizes[8]);
 
+/* Test hook: the neighbour contexts the parse derives from the blocks above and left of a block (NULL: none) —
+ * skip, intra/inter, interpolation filter, transform size (for max_tx), reference mode, compound reference, single
+ * reference p1 / p2 (vp9_pred_common.h / .c) — under the given sign biases of LAST / GOLDEN / ALTREF.
+ * tests/test_fe_contexts.py holds them against a table from the reference's own functions. */
+void vp9hip_fe_debug_contexts(const vp9hip_block *above, const vp9hip_block *left, const int32_t sign_bias[3], int max_tx,
+                              int32_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif
