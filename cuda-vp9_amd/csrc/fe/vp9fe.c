@@ -215,6 +215,7 @@ struct vp9hip_fe {
   int8_t lf_ref_deltas[4], lf_mode_deltas[2];
   int ref_sign_bias[4];
   int ref_map[8];
+  int prev_new_slot;
   SlotInfo slot[VP9HIP_FE_SLOTS];
   int width, height, ss_x, ss_y, bit_depth;  /* of the current / last frame (persist like VP9_COMMON's) */
   int mi_rows, mi_cols, sb_rows, sb_cols;
@@ -427,9 +428,11 @@ static void tile_col_bits(int mi_cols, int *min_log2, int *max_log2) { /* vp9_ge
   *max_log2 = mx - 1;
 }
 
+/* a buffer no reference map entry names; not the previous frame's either — a caller may still be fetching that one
+ * while this frame's kernels are queued */
 static int find_free_slot(const vp9hip_fe *fe) {
   for (int s = 0; s < VP9HIP_FE_SLOTS; ++s) {
-    int used = 0;
+    int used = s == fe->prev_new_slot;
     for (int i = 0; i < 8; ++i) used |= fe->ref_map[i] == s;
     if (!used) return s;
   }
@@ -2013,6 +2016,7 @@ int vp9hip_fe_create(vp9hip_fe **out, vp9hip_alloc_fn alloc, vp9hip_free_fn rele
   fe->checksums = getenv("VP9HIP_FE_CHECKSUMS") != NULL;
   fe->trace = getenv("VP9HIP_FE_TRACE") != NULL;
   for (int i = 0; i < 8; ++i) fe->ref_map[i] = -1;
+  fe->prev_new_slot = -1;
   pthread_mutex_init(&fe->mu, NULL);
   pthread_cond_init(&fe->cv_work, NULL);
   pthread_cond_init(&fe->cv_done, NULL);
@@ -2346,6 +2350,7 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
   ns->valid = 1;
   for (int i = 0; i < 8; ++i)
     if ((h->refresh_flags >> i) & 1) fe->ref_map[i] = new_slot;
+  fe->prev_new_slot = new_slot;
 
   /* stream state for the next frame (vp9_receive_compressed_data :473-488) */
   fe->last_show_frame = h->show_frame;

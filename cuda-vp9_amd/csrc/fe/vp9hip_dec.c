@@ -11,8 +11,9 @@
  * with -o the frames are written to the files the pattern names.  --summary prints vpxdec's line
  * (vpxdec.c:358-363) with the time spent decoding (file reading and hashing excluded).
  *
- * Frames are pipelined unless --serial: a second thread owns the GPU side — it waits for frame N - 1 and fetches it,
- * packs frame N and launches its kernels — while the first thread parses frame N + 1 (the front-end rotates three
+ * Frames are pipelined unless --serial: a second thread owns the GPU side — it packs frame N and queues its kernels
+ * behind those of frame N - 1, then fetches frame N - 1 as soon as that frame's own run is through — while the first
+ * thread parses frame N + 1 (the front-end rotates three
  * sets of output arrays, the coefficient arrays in page-locked memory).  A frame that is not shown is never
  * fetched; --noblit without --md5 fetches nothing unless --fetch is given.
  */
@@ -154,7 +155,8 @@ typedef struct {
 } Output;
 
 /* fetch pool slot `slot` and deliver it the way vpxdec does */
-static int deliver(Output *o, int slot, const vp9hip_frame_params *P) {
+/* ring_set >= 0: the frame's own run is waited for, not what was queued behind it (vp9hip_decoder_download_after) */
+static int deliver(Output *o, int slot, const vp9hip_frame_params *P, int ring_set) {
   if (o->noblit && !o->do_md5 && !o->fetch) {
     ++o->frame_out;
     return 0;
@@ -182,7 +184,7 @@ static int deliver(Output *o, int slot, const vp9hip_frame_params *P) {
   hf.ss_y = P->ss_y;
   hf.bit_depth = P->bit_depth;
   hf.hbd = P->hbd;
-  if (vp9hip_decoder_download(o->dec, slot, &hf)) {
+  if (ring_set >= 0 ? vp9hip_decoder_download_after(o->dec, slot, &hf, ring_set) : vp9hip_decoder_download(o->dec, slot, &hf)) {
     fprintf(stderr, "vp9hip_dec: %s\n", vp9hip_decoder_error(o->dec));
     return -1;
   }
@@ -225,9 +227,9 @@ static int deliver(Output *o, int slot, const vp9hip_frame_params *P) {
 typedef struct {
   vp9hip_decoder *dec;
   Output *out;
-  int pend, pend_slot;
+  int pend, pend_slot, pend_set;
   vp9hip_frame_params pend_params;
-  double t_begin, t_wait;
+  double t_begin;
   int failed;
   /* hand-over from the parsing thread (a rendezvous: the parser waits until the previous frame has been taken care of) */
   pthread_mutex_t mu;
@@ -236,25 +238,31 @@ typedef struct {
   int has, quit;
 } Gpu;
 
-static int gpu_flush(Gpu *g) {
-  if (!g->pend) return 0;
-  const double t0 = now_s();
-  if (vp9hip_decoder_sync(g->dec)) {
-    fprintf(stderr, "vp9hip_dec: %s\n", vp9hip_decoder_error(g->dec));
-    return -1;
+/* the frame in flight: fetched once its own run is through */
+static int gpu_flush(Gpu *g, int drain) {
+  int rc = 0;
+  if (g->pend) {
+    g->pend = 0;
+    if (g->pend_slot >= 0) rc = deliver(g->out, g->pend_slot, &g->pend_params, g->pend_set);
   }
-  g->t_wait += now_s() - t0;
-  g->pend = 0;
-  return g->pend_slot >= 0 ? deliver(g->out, g->pend_slot, &g->pend_params) : 0;
+  if (drain && !rc && vp9hip_decoder_sync(g->dec)) { /* also where a kernel-side error (loop-filter time-out) surfaces */
+    fprintf(stderr, "vp9hip_dec: %s\n", vp9hip_decoder_error(g->dec));
+    rc = -1;
+  }
+  return rc;
 }
 
 static int gpu_frame(Gpu *g, const vp9hip_fe_frame *fr, int serial) {
-  if (gpu_flush(g)) return -1;
-  if (fr->show_existing) return deliver(g->out, fr->show_slot, &fr->params);
+  if (fr->show_existing) {
+    if (gpu_flush(g, 0)) return -1;
+    if (vp9hip_decoder_sync(g->dec)) return -1; /* any earlier frame may be the one shown */
+    return deliver(g->out, fr->show_slot, &fr->params, -1);
+  }
   const double t0 = now_s();
   const vp9hip_frame_params *P = &fr->params;
   int ok = !vp9hip_decoder_alloc_slot(g->dec, fr->new_slot, P->width, P->height, P->ss_x, P->bit_depth, P->hbd, 0);
   ok = ok && !vp9hip_decoder_begin_frame_ex(g->dec, P, fr->blocks, fr->n_blocks, &fr->layout, fr->dqcoeff, VP9HIP_BEGIN_HOST_PERSISTENT);
+  const int set = vp9hip_decoder_current_set(g->dec);
   const int phases = VP9HIP_PHASE_INTRA | (fr->key_frame || fr->intra_only ? 0 : VP9HIP_PHASE_INTER) | (fr->filter_level ? VP9HIP_PHASE_LF : 0);
   ok = ok && !vp9hip_decoder_run(g->dec, phases, fr->ref_slot, fr->new_slot, NULL, fr->filter_level ? &fr->lf_thresh : NULL);
   g->t_begin += now_s() - t0;
@@ -262,10 +270,14 @@ static int gpu_frame(Gpu *g, const vp9hip_fe_frame *fr, int serial) {
     fprintf(stderr, "vp9hip_dec: %s\n", vp9hip_decoder_error(g->dec));
     return -1;
   }
+  /* this frame's kernels are queued behind the previous frame's: now fetch the previous one (the front-end never hands
+   * out the previous frame's buffer, so nothing queued writes what is being fetched) */
+  if (gpu_flush(g, 0)) return -1;
   g->pend = 1;
   g->pend_slot = fr->show_frame ? fr->new_slot : -1;
+  g->pend_set = set;
   g->pend_params = *P;
-  return serial ? gpu_flush(g) : 0;
+  return serial ? gpu_flush(g, 1) : 0;
 }
 
 static void *gpu_main(void *arg) {
@@ -456,17 +468,17 @@ int main(int argc, char **argv) {
       pthread_join(th, NULL);
       if (g.failed) rc_all = 1;
     }
-    if (!rc_all && gpu_flush(&g)) rc_all = 1;
+    if (!rc_all && gpu_flush(&g, 1)) rc_all = 1;
     const double dt = now_s() - t_loop - out.t_hash;
     if (summary)
       fprintf(stderr, "%d decoded frames/%d showed frames in %.0f us (%.2f fps)\n", frames_in, out.frame_out, dt * 1e6,
               out.frame_out / (dt > 0 ? dt : 1));
     if (stats && frames_in)
       fprintf(stderr,
-              "vp9hip_dec: per frame: parse %.3f ms, hand-over wait %.3f ms | GPU thread: pack + launch %.3f ms, wait for the GPU %.3f ms, "
+              "vp9hip_dec: per frame: parse %.3f ms, hand-over wait %.3f ms | GPU thread: pack + launch %.3f ms, wait for the frame's run + "
               "fetch %.3f ms, hash/write %.3f ms\n",
-              1e3 * t_parse / frames_in, 1e3 * t_hand / frames_in, 1e3 * g.t_begin / frames_in, 1e3 * g.t_wait / frames_in,
-              1e3 * out.t_fetch / frames_in, 1e3 * out.t_hash / frames_in);
+              1e3 * t_parse / frames_in, 1e3 * t_hand / frames_in, 1e3 * g.t_begin / frames_in, 1e3 * out.t_fetch / frames_in,
+              1e3 * out.t_hash / frames_in);
     for (int p = 0; p < 3; ++p)
       if (out.host[p]) vp9hip_decoder_host_free(dec, out.host[p]);
     vp9hip_decoder_sync(dec);

@@ -40,6 +40,7 @@ struct ListSet {
 struct vp9hip_decoder {
   vp9hip_ctx *ctx;
   hipStream_t copy_stream;
+  hipStream_t dl_stream;  // frame fetches that must not queue behind the next frame's kernels
   char err[512];
   Slot slots[VP9HIP_POOL_SLOTS];
   ListSet sets[VP9HIP_RING_SETS];
@@ -117,6 +118,7 @@ extern "C" int vp9hip_decoder_create(int device, vp9hip_decoder **out) {
     return rc;  // text in vp9hip_last_error(NULL)
   }
   bool ok = hipStreamCreateWithFlags(&dec->copy_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&dec->dl_stream, hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; i < VP9HIP_RING_SETS && ok; ++i) {
     ListSet *s = &dec->sets[i];
     ok = vp9hip_packer_create_ex(&s->pk, pinned_alloc, pinned_free, NULL) == VP9HIP_OK &&
@@ -136,6 +138,7 @@ extern "C" void vp9hip_decoder_destroy(vp9hip_decoder *dec) {
   (void)hipSetDevice(dec->ctx->device);
   (void)hipStreamSynchronize(dec->ctx->stream);
   if (dec->copy_stream) (void)hipStreamSynchronize(dec->copy_stream);
+  if (dec->dl_stream) (void)hipStreamSynchronize(dec->dl_stream);
   for (int s = 0; s < VP9HIP_POOL_SLOTS; ++s)
     for (int p = 0; p < 3; ++p)
       if (dec->slots[s].f.plane[p]) (void)hipFree(dec->slots[s].f.plane[p]);
@@ -153,6 +156,7 @@ extern "C" void vp9hip_decoder_destroy(vp9hip_decoder *dec) {
   for (int p = 0; p < 3; ++p)
     if (dec->d_res[p].p) (void)hipFree(dec->d_res[p].p);
   if (dec->copy_stream) (void)hipStreamDestroy(dec->copy_stream);
+  if (dec->dl_stream) (void)hipStreamDestroy(dec->dl_stream);
   vp9hip_destroy(dec->ctx);
   free(dec);
 }
@@ -259,6 +263,30 @@ extern "C" int vp9hip_decoder_download(vp9hip_decoder *dec, int slot, const vp9h
   }
   int rc = vp9hip_sync(dec->ctx);
   if (rc) DEC_FAIL(dec, rc, "%s", vp9hip_last_error(dec->ctx));
+  return VP9HIP_OK;
+}
+
+// A frame fetched as soon as ITS run is through, while later frames' kernels are already queued on the launch
+// stream: the copy waits for the `done` event of the ring set the frame was run from, on a stream of its own.
+extern "C" int vp9hip_decoder_download_after(vp9hip_decoder *dec, int slot, const vp9hip_host_frame *dst, int ring_set) {
+  if (!dec) return VP9HIP_EINVAL;
+  if (slot < 0 || slot >= VP9HIP_POOL_SLOTS || !dec->slots[slot].used)
+    DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download_after: slot %d holds no frame", slot);
+  if (ring_set < 0 || ring_set >= VP9HIP_RING_SETS || !dec->sets[ring_set].done_pending)
+    DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download_after: ring set %d has no run in flight", ring_set);
+  if (!host_frame_ok(dst)) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download_after: bad host frame");
+  const Slot *s = &dec->slots[slot];
+  if (dst->width != s->f.width[0] || dst->height != s->f.height[0] || (dst->hbd != 0) != (s->f.hbd != 0) || dst->ss_x != s->ss)
+    DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download_after: host frame geometry differs from slot %d", slot);
+  const int bps = s->f.hbd ? 2 : 1;
+  DEC_HIP(dec, hipSetDevice(dec->ctx->device));
+  DEC_HIP(dec, hipStreamWaitEvent(dec->dl_stream, dec->sets[ring_set].done, 0));
+  for (int p = 0; p < 3; ++p) {
+    if (dst->stride[p] < s->f.awidth[p]) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download_after: plane %d stride too small", p);
+    DEC_HIP(dec, hipMemcpy2DAsync(dst->plane[p], (size_t)dst->stride[p] * bps, s->f.plane[p], (size_t)s->f.stride[p] * bps,
+                                  (size_t)s->f.awidth[p] * bps, s->f.aheight[p], hipMemcpyDeviceToHost, dec->dl_stream));
+  }
+  DEC_HIP(dec, hipStreamSynchronize(dec->dl_stream));
   return VP9HIP_OK;
 }
 

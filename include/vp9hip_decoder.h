@@ -55,6 +55,11 @@ int vp9hip_decoder_alloc_slot(vp9hip_decoder *dec, int slot, int width, int heig
 /* Host -> pool slot (allocates / re-shapes the slot as needed) and pool slot -> host.  Synchronous. */
 int vp9hip_decoder_upload(vp9hip_decoder *dec, int slot, const vp9hip_host_frame *src);
 int vp9hip_decoder_download(vp9hip_decoder *dec, int slot, const vp9hip_host_frame *dst);
+/* Pool slot -> host as soon as the run of ring set `ring_set` (vp9hip_decoder_current_set after the frame's
+ * begin_frame) is through — not behind whatever was enqueued after it: for callers that keep the next frame's
+ * kernels queued while they fetch this one.  Waits for the copy.  Errors of the kernels themselves (a loop-filter
+ * row that gave up waiting) are still reported by vp9hip_decoder_sync. */
+int vp9hip_decoder_download_after(vp9hip_decoder *dec, int slot, const vp9hip_host_frame *dst, int ring_set);
 /* The slot's device descriptor (for callers that use the batched entry points directly). */
 int vp9hip_decoder_slot_frame(vp9hip_decoder *dec, int slot, vp9hip_frame *out);
 

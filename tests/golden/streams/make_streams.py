@@ -65,6 +65,9 @@ STREAMS = {
     "S-2160": (3840, 2160, 30, 2160, 23, -17, 8, "420", 0.0, 8, ["--cpu-used=4", "--cq-level=32", "--tile-columns=4", "--lag-in-frames=0", "--passes=1"], True),
     # BASELINE.json config 1's exact geometry (FoodMarket2: 3840x2176 = 60x34 whole superblocks), two-pass with alt-ref
     "S-2176": (3840, 2176, 12, 2176, 9, -5, 8, "420", 0.1, 0, ["--good", "--cpu-used=4", "--cq-level=30", "--tile-columns=4", "--passes=2", "--auto-alt-ref=1", "--lag-in-frames=8"], True),
+    # the same motion as S-1440 at a lower rate (cq 44: a fifth of the coefficients) — what a stream of ordinary
+    # quality asks of the entropy stage
+    "S-1440-q44": (2560, 1440, 60, 1440, 5, 3, 8, "420", 0.1, 0, ["--cpu-used=2", "--cq-level=44", "--tile-columns=3", "--lag-in-frames=0", "--passes=1"], True),
     "S-1080-10": (1920, 1080, 30, 1080, 7, 4, 10, "420", 0.1, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=2", "--cq-level=28", "--tile-columns=2", "--lag-in-frames=0", "--passes=1"], True),
 }
 

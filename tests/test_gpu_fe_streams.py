@@ -42,7 +42,7 @@ def test_standalone_decoder_md5(name):
     check(SMALL, name, "--serial", "--threads=1")
 
 
-@pytest.mark.parametrize("name", ["S-1440", "S-2160", "S-2176", "S-1080-10"])
+@pytest.mark.parametrize("name", ["S-1440", "S-1440-q44", "S-2160", "S-2176", "S-1080-10"])
 def test_standalone_decoder_md5_baseline_sized(name):
     if not os.path.exists(os.path.join(BIG, name + ".ivf")):
         pytest.skip("tests/streams_big not generated (make_streams.py --big)")
