@@ -118,7 +118,6 @@ extern "C" int vp9hip_decoder_create(int device, vp9hip_decoder **out) {
     return rc;  // text in vp9hip_last_error(NULL)
   }
   bool ok = hipStreamCreateWithFlags(&dec->copy_stream, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&dec->dl_stream, hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; i < VP9HIP_RING_SETS && ok; ++i) {
     ListSet *s = &dec->sets[i];
     ok = vp9hip_packer_create_ex(&s->pk, pinned_alloc, pinned_free, NULL) == VP9HIP_OK &&
@@ -280,6 +279,10 @@ extern "C" int vp9hip_decoder_download_after(vp9hip_decoder *dec, int slot, cons
     DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download_after: host frame geometry differs from slot %d", slot);
   const int bps = s->f.hbd ? 2 : 1;
   DEC_HIP(dec, hipSetDevice(dec->ctx->device));
+  // created on first use: a process that runs several decoders side by side without ever fetching early keeps the
+  // stream-to-hardware-queue layout it had (HIP spreads a process's streams over a handful of hardware queues; one
+  // more stream per decoder put all eight launch streams of bench.py's multi-stream leg on the same queue)
+  if (!dec->dl_stream) DEC_HIP(dec, hipStreamCreateWithFlags(&dec->dl_stream, hipStreamNonBlocking));
   DEC_HIP(dec, hipStreamWaitEvent(dec->dl_stream, dec->sets[ring_set].done, 0));
   for (int p = 0; p < 3; ++p) {
     if (dst->stride[p] < s->f.awidth[p]) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_download_after: plane %d stride too small", p);
