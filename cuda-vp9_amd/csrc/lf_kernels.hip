@@ -828,9 +828,10 @@ __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restr
                           gate_done, gate_expected, sb_rows, hand, gen);
 }
 
-// The island walk and the loop filter of a frame as ONE launch: workgroups [0, sb_rows * planes) are the
-// filter's rows (dispatched first, so they are resident before the islands flood the GPU: a filter row
-// waits, bounded, for islands, and islands never wait for anything), the rest walk one island each.  No
+// The island walk and the loop filter of a frame as ONE launch: the filter's rows and one workgroup per island.
+// islands_first_flag == 0: workgroups [0, sb_rows * planes) are the rows (dispatched first, so they are resident
+// before the islands flood the GPU: a filter row waits, bounded, for islands, and islands never wait for
+// anything); != 0: the islands come first in the grid (see the launch site).  No
 // second stream, no fork / join events between the transforms, this pair and the next frame's convolve —
 // every such dependency packet cost the command processor several microseconds between two kernels
 // (rocprofv3 trace of bench.py, DESIGN.md §3.4: 12 us before and 37 us after the pair as two launches).
@@ -841,10 +842,14 @@ __global__ __launch_bounds__(256) void walk_lf_kernel(const vp9hip_lfm *__restri
                                                       const vp9hip_intra_task *__restrict__ tasks,
                                                       const vp9hip_intra_island *__restrict__ islands,
                                                       const int32_t *__restrict__ wave_off, ResidDev rd,
-                                                      const int32_t *__restrict__ coeffs, lf_granule *hand, unsigned gen) {
+                                                      const int32_t *__restrict__ coeffs, lf_granule *hand, unsigned gen,
+                                                      int islands_first_flag) {
   const int n_lf = sb_rows * planes;
-  if ((int)blockIdx.x >= n_lf) {
-    const int island = (int)blockIdx.x - n_lf;
+  const int n_isl = (int)gridDim.x - n_lf;
+  const bool islands_first = islands_first_flag != 0;
+  const int lf_index = islands_first ? (int)blockIdx.x - n_isl : (int)blockIdx.x;
+  if (islands_first ? (int)blockIdx.x < n_isl : (int)blockIdx.x >= n_lf) {
+    const int island = islands_first ? (int)blockIdx.x : (int)blockIdx.x - n_lf;
     if (coeffs != nullptr) {
       // the residual of the island's coded tasks first (no waves: every task at once, eight at a time), into
       // the residual scratch the walk then adds from — what intra_residual_kernel does as a launch of its own
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(256) void walk_lf_kernel(const vp9hip_lfm *__restri
   __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
   __shared__ unsigned ctls[2 * 256];
   __shared__ unsigned flags[2];
-  const int sr = (int)blockIdx.x % sb_rows, pl = (int)blockIdx.x / sb_rows;
+  const int sr = lf_index % sb_rows, pl = lf_index / sb_rows;
   int *hprev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
   int *hmine = progress + pl * sb_rows + sr;
   int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
@@ -1109,10 +1114,18 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
     const FrameDev f = to_dev(frame);
     const ResidDev rd = resid_dev(ctx, frame);
     const int grid = sb_rows * planes + n_islands;
+    // Grid order.  One context in the process: the filter's rows first — they are resident before the islands flood
+    // the GPU and the chain starts at once (4 % of the frame).  Several contexts: launches of different contexts run
+    // side by side, and rows that are resident and waiting for their islands can take the slots those islands need
+    // (in-order dispatch per hardware queue: a launch's islands come after ITS rows, but not after the rows of the
+    // other launches) until a row's bounded wait runs out — then the islands go first: a row only ever waits for
+    // workgroups dispatched before it, whatever else is in flight.  VP9HIP_ISLANDS_FIRST=0/1 overrides.
+    static const char *order_env = getenv("VP9HIP_ISLANDS_FIRST");
+    const int islands_first = order_env ? atoi(order_env) != 0 : vp9hip_live_contexts() > 1;
 #define WALK_LF(PIX, SH)                                                                                              \
   hipLaunchKernelGGL((walk_lf_kernel<PIX, SH>), dim3(grid), dim3(256), 0, ctx->stream, d_lfm, sb_cols, sb_rows, planes, th, f, \
                      frame->aheight[0] / 8, (int *)ctx->scratch, ctx->lf_err_flag, d_gate, d_sb_expected, d_tasks, d_islands, \
-                     d_wave_off, rd, k_coeffs, (lf_granule *)ctx->lf_hand, gen)
+                     d_wave_off, rd, k_coeffs, (lf_granule *)ctx->lf_hand, gen, islands_first)
     unsigned gen = 0;
     {
       int rc2 = lf_handoff_buffer(ctx, frame, sb_rows, &gen);

@@ -7,6 +7,11 @@ static char g_err[512] = "no context";
 
 extern "C" int vp9hip_abi_version(void) { return VP9HIP_ABI_VERSION; }
 
+// contexts alive in this process: with more than one, launches of different contexts run side by side and the fused
+// walk + filter launch orders its workgroups for safety rather than for the shortest chain (lf_kernels.hip)
+static int g_live_contexts = 0;
+int vp9hip_live_contexts(void) { return __atomic_load_n(&g_live_contexts, __ATOMIC_RELAXED); }
+
 extern "C" int vp9hip_create(int device, vp9hip_ctx **out) {
   if (!out) return VP9HIP_EINVAL;
   *out = NULL;
@@ -32,12 +37,14 @@ extern "C" int vp9hip_create(int device, vp9hip_ctx **out) {
   hipDeviceProp_t prop;
   ctx->cu_count = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
   ctx->err[0] = 0;
+  __atomic_add_fetch(&g_live_contexts, 1, __ATOMIC_RELAXED);
   *out = ctx;
   return VP9HIP_OK;
 }
 
 extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   if (!ctx) return;
+  __atomic_sub_fetch(&g_live_contexts, 1, __ATOMIC_RELAXED);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);

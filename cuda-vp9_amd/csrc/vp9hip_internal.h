@@ -87,6 +87,7 @@ static inline int frame_ok(const vp9hip_frame *f) {
 }
 
 int vp9hip_ensure_scratch(vp9hip_ctx *ctx, size_t bytes);
+int vp9hip_live_contexts(void);  /* contexts alive in this process */
 int vp9hip_ensure_resid(vp9hip_ctx *ctx, const vp9hip_frame *frame);
 int vp9hip_lf_zero_counters(vp9hip_ctx *ctx, const vp9hip_frame *frame, hipStream_t st);
 int vp9hip_islands_prepare(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,

@@ -85,3 +85,15 @@ def test_standalone_decoder_refuses_a_damaged_stream(tmp_path):
     assert lines[:2] == want[:2]  # the frames before the damage are right
     # the damaged frame either fails to parse (error exit) or decodes to something else; it never takes the process down
     assert r.returncode in (0, 1) and (r.returncode == 1 or lines[2:3] != want[2:3])
+
+
+@pytest.mark.parametrize("order", ["0", "1"])
+def test_both_grid_orders_of_the_fused_walk_and_filter_launch(order):
+    """VP9HIP_ISLANDS_FIRST: the filter's rows first (one context in the process, the default there) or the islands first
+    (what a process with several contexts gets, so that a row never waits for a workgroup dispatched after it)."""
+    ivf = os.path.join(SMALL, "s704_8.ivf")
+    r = subprocess.run([DEC, "--md5", "-o", "img-%wx%h-%4.i420", ivf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env=dict(os.environ, VP9HIP_ISLANDS_FIRST=order))
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-500:]
+    got = [l for l in r.stdout.decode().splitlines() if re.match(r"^[0-9a-f]{32}  img-", l)]
+    assert got == golden(os.path.join(SMALL, "s704_8.md5"))
