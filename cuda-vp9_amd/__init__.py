@@ -101,9 +101,9 @@ class Packed(ctypes.Structure):
     _fields_ = [("inter", ctypes.c_void_p), ("n_inter", ctypes.c_int32), ("inter_class_count", ctypes.c_int32 * 6),
                 ("txb", ctypes.c_void_p), ("n_txb", ctypes.c_int32), ("txb_size_count", ctypes.c_int32 * 4),
                 ("intra_island_tasks", ctypes.c_void_p), ("n_intra_island_tasks", ctypes.c_int32),
-                ("islands", ctypes.c_void_p), ("n_islands", ctypes.c_int32),
+                ("islands", ctypes.c_void_p), ("n_islands", ctypes.c_int32), ("n_islands_lds", ctypes.c_int32),
                 ("island_wave_off", ctypes.c_void_p), ("n_island_wave_off", ctypes.c_int32),
-                ("island_sb_expected", ctypes.c_void_p),
+                ("island_sb_expected", ctypes.c_void_p), ("island_row_pos", ctypes.c_void_p),
                 ("intra_big_tasks", ctypes.c_void_p), ("n_intra_big_tasks", ctypes.c_int32),
                 ("big_wave_start", ctypes.c_void_p), ("n_big_waves", ctypes.c_int32),
                 ("intra_decode_order", ctypes.c_void_p), ("n_intra", ctypes.c_int32),
@@ -424,6 +424,8 @@ class Packer:
             intra_islands=_arr(out.islands, out.n_islands, ISLAND_DTYPE),
             intra_island_wave_off=_arr(out.island_wave_off, out.n_island_wave_off, np.int32),
             island_sb_expected=_arr(out.island_sb_expected, out.sb_rows * out.sb_cols, np.int32),
+            n_islands_lds=out.n_islands_lds,
+            island_row_pos=_arr(out.island_row_pos, out.sb_rows if out.island_row_pos else 0, np.int32),
             intra_big_tasks=_arr(out.intra_big_tasks, out.n_intra_big_tasks, INTRA_DTYPE),
             intra_big_wave_start=_arr(out.big_wave_start, out.n_big_waves + 1, np.int32),
             intra_decode_order=_arr(out.intra_decode_order, out.n_intra, INTRA_DTYPE),
@@ -462,6 +464,15 @@ class DevBuf:
         if self.ptr:
             lib().vp9hip_free(self.ctx.handle, self.ptr)
             self.ptr = None
+
+    def offset(self, nbytes):
+        """A view `nbytes` into this allocation (not owning: never freed)."""
+        return _DevView(self.ptr + int(nbytes))
+
+
+class _DevView:
+    def __init__(self, ptr):
+        self.ptr = ptr
 
 
 class DevFrame:
@@ -572,21 +583,19 @@ class Context:
             ctypes.c_void_p(d_wave_off.ptr), ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
             ctypes.byref(frame.desc)))
 
-    def intra_residual_begin(self, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame):
-        """Optional head start of the island calls (vp9hip_intra_residual_begin): call before the frame's
-        convolve / transform launches with the lists the island call will get."""
-        self.check(lib().vp9hip_intra_residual_begin(
-            self.handle, ctypes.c_void_p(d_tasks.ptr), ctypes.c_void_p(d_islands.ptr), int(n_islands),
-            ctypes.c_void_p(d_wave_off.ptr), ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
-            ctypes.byref(frame.desc)))
-
-    def intra_islands_lf(self, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, d_sb_expected, d_lfm, sb_rows,
+    def intra_islands_lf(self, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, d_sb_expected, row_pos, d_lfm, sb_rows,
                          sb_cols, thresh, frame, planes=3):
-        """Island walk and loop filter side by side (vp9hip_intra_islands_lf)."""
+        """Island walk (in LDS) and loop filter as one launch (vp9hip_intra_islands_lf).  row_pos: host int32 array
+        (sb_rows entries) or None = every island in front of the filter's rows."""
+        rp = None
+        if row_pos is not None:
+            rp = np.ascontiguousarray(row_pos, np.int32)
+            assert len(rp) == sb_rows
         self.check(lib().vp9hip_intra_islands_lf(
             self.handle, ctypes.c_void_p(d_tasks.ptr), ctypes.c_void_p(d_islands.ptr), int(n_islands),
             ctypes.c_void_p(d_wave_off.ptr), ctypes.c_void_p(d_coeffs.ptr if d_coeffs is not None else None),
-            ctypes.c_void_p(d_sb_expected.ptr), ctypes.c_void_p(d_lfm.ptr), int(sb_rows), int(sb_cols),
+            ctypes.c_void_p(d_sb_expected.ptr), ctypes.c_void_p(rp.ctypes.data if rp is not None else None),
+            ctypes.c_void_p(d_lfm.ptr), int(sb_rows), int(sb_cols),
             ctypes.byref(thresh), ctypes.byref(frame.desc), int(planes)))
 
     def loop_filter_frame(self, d_lfm, sb_rows, sb_cols, thresh, frame, planes=3):

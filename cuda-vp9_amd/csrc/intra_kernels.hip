@@ -169,11 +169,11 @@ __device__ __forceinline__ void predict_column(int mode, int c, const int *E, bo
   }
 }
 
-template <int N, bool HBD>
+template <int N, bool HBD, int PITCH = TPITCH>
 __device__ __forceinline__ void row_pass(int *tile, int t, int tx_type, bool lossless) {
   int v[N];
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = tile[t * TPITCH + k];
+  for (int k = 0; k < N; ++k) v[k] = tile[t * PITCH + k];
   if (lossless) {
     if constexpr (N == 4) txfm::iwht4(v, true);
   } else if (N < 32 && (tx_type & 2)) {
@@ -182,14 +182,14 @@ __device__ __forceinline__ void row_pass(int *tile, int t, int tx_type, bool los
     txfm::idct1d<N, HBD>(v);
   }
 #pragma unroll
-  for (int k = 0; k < N; ++k) tile[t * TPITCH + k] = v[k];
+  for (int k = 0; k < N; ++k) tile[t * PITCH + k] = v[k];
 }
 
-template <int N, bool HBD>
+template <int N, bool HBD, int PITCH = TPITCH>
 __device__ __forceinline__ void col_pass(const int *tile, int t, int tx_type, bool lossless, int *v) {
   constexpr int shift = N == 4 ? 4 : (N == 8 ? 5 : 6);
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = tile[k * TPITCH + t];
+  for (int k = 0; k < N; ++k) v[k] = tile[k * PITCH + t];
   if (lossless) {
     if constexpr (N == 4) txfm::iwht4(v, false);
     return;
@@ -228,13 +228,6 @@ __device__ __forceinline__ void block_residual(const vp9hip_intra_task &tk, int 
   }
 }
 
-// Where intra_residual_kernel leaves the residual of every coded island task and the island walk
-// picks it up: one int32 per sample at the sample's position, planes back to back (context scratch).
-struct ResidDev {
-  int *p;
-  int off[3], stride[3];
-};
-
 template <int N, typename Pix, bool HBD>
 __device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t, const int *E, const int *tile,
                                              bool coded, int dc_coeff, int dc_kind, const FrameDev &f) {
@@ -244,29 +237,6 @@ __device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t,
   if (coded) {
     int v[N];
     block_residual<N, HBD>(tk, t, tile, dc_coeff, dc_kind, v);
-    const int maxv = (1 << f.bit_depth) - 1;
-#pragma unroll
-    for (int k = 0; k < N; ++k) p[k] = clip_to(txfm::add32(p[k], v[k]), maxv);
-  }
-  const int pl = tk.plane;
-  const int x = tk.x + t;
-  if (x >= f.awidth[pl]) return;
-  Pix *dst = (Pix *)f.plane[pl] + (size_t)tk.y * f.stride[pl] + x;
-  const int rows = min(N, f.aheight[pl] - (int)tk.y);
-#pragma unroll
-  for (int k = 0; k < N; ++k)
-    if (k < rows) dst[(size_t)k * f.stride[pl]] = (Pix)p[k];
-}
-
-// The walk's form: the residual was computed ahead of the walk (it does not depend on the neighbours)
-// and v[] was loaded before the edges were assembled.
-template <int N, typename Pix>
-__device__ __forceinline__ void finish_block_res(const vp9hip_intra_task &tk, int t, const int *E, const int *v,
-                                                 bool coded, const FrameDev &f) {
-  if (t >= N) return;
-  int p[N];
-  predict_column<N>(tk.mode, t, E, tk.flags & 1, (tk.flags >> 1) & 1, f.bit_depth, p);
-  if (coded) {
     const int maxv = (1 << f.bit_depth) - 1;
 #pragma unroll
     for (int k = 0; k < N; ++k) p[k] = clip_to(txfm::add32(p[k], v[k]), maxv);
@@ -382,184 +352,398 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
   }
 }
 
-// ---- residual ahead of the walk ----------------------------------------------------------------
-// The residual of an intra block depends on its coefficients only; the prediction depends on the
-// neighbours.  intra_residual_kernel runs the inverse transforms of every coded island task in
-// parallel (no waves) into ResidDev; the walk (intra_chunk_res) then has only edge assembly +
-// prediction + add on its dependent chain, and its residual loads are issued before the edge loads.
-template <int N, bool HBD>
-__device__ __forceinline__ void residual_block(const vp9hip_intra_task &tk, int t, int *tile, int dc_coeff, int dc_kind,
-                                               const ResidDev &rd, const FrameDev &f) {
-  if (t >= N) return;
-  int v[N];
-  block_residual<N, HBD>(tk, t, tile, dc_coeff, dc_kind, v);
-  const int pl = tk.plane;
-  const int x = tk.x + t;
-  if (x >= f.awidth[pl]) return;
-  int *dst = rd.p + rd.off[pl] + (size_t)tk.y * rd.stride[pl] + x;
-  const int rows = min(N, f.aheight[pl] - (int)tk.y);
-#pragma unroll
-  for (int k = 0; k < N; ++k)
-    if (k < rows) dst[(size_t)k * rd.stride[pl]] = v[k];
+// =============================================================================================
+// Island walk in LDS.  An island (vp9hip.h) whose window fits is walked without touching the frame
+// between its first and its last wave:
+//   1. the task records go to LDS; their bounding box per plane gives the window (one row above, one
+//      column to the left, four columns to the right: the above-right samples of a 4x4 block);
+//   2. the window is read from the frame once (everything around the island's blocks is final: inter
+//      prediction + residual ran before, and blocks of OTHER islands are never read — an edge between
+//      two intra blocks would have put them into one island);
+//   3. the residual of every coded block (inverse transform, all blocks side by side, no waves) is
+//      stored INTO the window at the block's own position as int16, saturated: a block's samples are
+//      dead until the block is predicted, and clip(pred + res) = clip(pred + sat16(res)) because
+//      0 <= pred < 4096 (|res| < 2^27 for every transform, so pred + res never wraps either);
+//   4. the waves: edge assembly, prediction, + residual, clip — LDS to LDS, one sample per lane;
+//   5. the island's blocks are written to the frame, row pieces of four samples; then the
+//      per-superblock completion marks for the loop filter (vp9hip_intra_islands_lf).
+// The dependent chain of a wave is a handful of LDS round trips instead of three memory round trips
+// (task record, edge samples written by the wave before, store drain), and the frame is read and
+// written once per island instead of once per wave.
+constexpr int ISL_TILE = VP9HIP_ISLAND_TILE_ELEMS;
+constexpr int ISL_TASKS = VP9HIP_ISLAND_MAX_TASKS;
+constexpr int ISL_TX32 = VP9HIP_ISLAND_MAX_TX32;
+constexpr int ISL_POOL_PITCH = 17;                       // 16x16 and smaller: 16 rows of 17 dwords per slot
+constexpr int ISL_POOL_SLOT = 16 * ISL_POOL_PITCH;       // 272
+constexpr int ISL_POOL_INTS = SLOTS * ISL_POOL_SLOT;     // 2176: also two 32x33 tiles (1088 each)
+constexpr int ISL_MARKS = 96;
+
+struct IslandLds {
+  short tile[ISL_TILE];
+  int pool[ISL_POOL_INTS];
+  int edge[SLOTS][ESIZE];
+  vp9hip_intra_task tasks[ISL_TASKS];
+  int box[3][4];        // x0, y0, x1, y1 of the blocks of a plane
+  int idx0[3], pitch[3];  // sample (x, y) of plane p is tile[idx0[p] + y * pitch[p] + x]
+  int n32, nmarks, bad;
+  short list32[ISL_TX32];
+  int marks[ISL_MARKS];
+  short woff[ISL_TASKS + 2];  // wave offsets (relative to the island's first task)
+};
+
+// LDS of the walk through memory (islands that do not fit)
+struct IslandMemLds {
+  int edge[SLOTS][ESIZE];
+  int tiles[SLOTS][32 * TPITCH];
+};
+
+// sum over the 32 lanes of a slot (all of them active)
+__device__ __forceinline__ int slot_sum32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);  // row_mirror
+  v += __builtin_amdgcn_ds_swizzle(v, 0x401f);                    // lane ^ 16
+  return v;
 }
 
+// One predicted sample (r, c) of a bs x bs block: predict_column's forms with the block size at run time
+// (vpx_dsp/intrapred.c; 4x4 specials :308-373).
+__device__ __forceinline__ int predict_px(int mode, int bs, int r, int c, const int *E, int dc, int maxv) {
+  const int *A = E + 1;
+  switch (mode) {
+    case 0: return dc;
+    case 1: return A[c];
+    case 2: return E[-1 - r];
+    case 9: return clip_to(E[-1 - r] + A[c] - A[-1], maxv);
+    case 3: {
+      const int i = r + c;
+      if (bs == 4) return (i == 6) ? A[7] : AVG3(A[i], A[i + 1], A[i + 2]);
+      return (i < bs - 1) ? AVG3(A[i], A[i + 1], A[i + 2]) : A[bs - 1];
+    }
+    case 8: {
+      const int k = r >> 1, i = c + k;
+      if (bs != 4 && r >= 2 && c >= bs - 1 - k) return A[bs - 1];
+      return (r & 1) ? AVG3(A[i], A[i + 1], A[i + 2]) : AVG2(A[i], A[i + 1]);
+    }
+    case 7: {
+      const int i = r + (c >> 1);
+      if (i >= bs - 1) return E[-bs];
+      if (!(c & 1)) return AVG2(E[-1 - i], E[-2 - i]);
+      return AVG3(E[-1 - i], E[-2 - i], E[-1 - (i + 2 < bs ? i + 2 : bs - 1)]);
+    }
+    case 4: {
+      const int d = c - r;
+      return AVG3(E[d - 1], E[d], E[d + 1]);
+    }
+    case 5: {
+      const int k = (r >> 1) < c ? (r >> 1) : c;
+      const int rr = r - 2 * k, cc = c - k;
+      if (rr == 0) return AVG2(E[cc], E[cc + 1]);
+      if (rr == 1) return AVG3(E[cc - 1], E[cc], E[cc + 1]);
+      return AVG3(E[2 - rr], E[1 - rr], E[-rr]);
+    }
+    case 6: {
+      const int k = r < (c >> 1) ? r : (c >> 1);
+      const int rr = r - k, cc = c - 2 * k;
+      if (cc == 0) return AVG2(E[-rr], E[-rr - 1]);
+      if (cc == 1) return AVG3(E[1 - rr], E[-rr], E[-rr - 1]);
+      return AVG3(E[cc - 2], E[cc - 1], E[cc]);
+    }
+    default: return 0;
+  }
+}
+
+__device__ __forceinline__ short sat16(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
 template <bool HBD>
-__device__ __forceinline__ void residual_chunk(int (*tiles)[32 * TPITCH], const vp9hip_intra_task *__restrict__ tasks,
-                                               int index, bool active, const int32_t *__restrict__ coeffs,
-                                               const ResidDev &rd, const FrameDev &f) {
-  const int slot = threadIdx.x / SLOT, t = threadIdx.x % SLOT;
-  vp9hip_intra_task tk;
-  memset(&tk, 0, sizeof(tk));
-  if (active) tk = tasks[index];
+__device__ __forceinline__ int dc_only_shift(int dc, int shift) {  // txfm::dc_only with the block size at run time
+  int out;
+  if constexpr (HBD) {
+    out = txfm::rs14_i64((txfm::i64)dc * txfm::kCos[16]);
+    out = txfm::rs14_i64((txfm::i64)out * txfm::kCos[16]);
+  } else {
+    out = txfm::rs14_i32((int)(short)dc * txfm::kCos[16]);
+    out = txfm::rs14_i32(txfm::mul32(out, txfm::kCos[16]));
+  }
+  return txfm::add32(out, 1 << (shift - 1)) >> shift;
+}
+
+// forms a coded block's residual takes (vp9_idct.c:119-204): 0 full transform, 1 DC only, 2 lossless DC only,
+// 3 the slot holds the residual itself (residual-plane mode)
+__device__ __forceinline__ int resid_kind(const vp9hip_intra_task &tk) {
   const int bs = 4 << tk.tx_size;
   const bool lossless = tk.tx_type & 0x80;
-  const bool identity = tk.tx_type & 0x40;
-  const bool coded = active && tk.eob > 0;
-  int *tile = tiles[slot];
-  int dc_kind = 0, dc_coeff = 0;
-  if (coded) {  // same selection of forms as intra_chunk
+  if (tk.tx_type & 0x40) return 3;
+  if (!lossless && ((tk.tx_type & 3) == 0 || bs == 32) && (bs == 4 ? tk.eob <= 1 : tk.eob == 1)) return 1;
+  if (lossless && tk.eob <= 1) return 2;
+  return 0;
+}
+
+// column t of a block's residual -> the window
+template <int N>
+__device__ __forceinline__ void store_resid_col(short *dst, int pitch, const int *v) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) dst[k * pitch] = sat16(v[k]);
+}
+
+template <int N, bool HBD, int PITCH>
+__device__ __forceinline__ void island_full_transform(IslandLds &S, const vp9hip_intra_task &tk, int t, int *pt,
+                                                      const int32_t *__restrict__ coeffs) {
+  // t < N lanes of one wavefront; LDS of one wavefront is in order, so a fence per stage is enough (slot_sync)
+  const bool lossless = tk.tx_type & 0x80;
+  const int tt = tk.tx_type & 3;
+  if (t < N) {
     const int32_t *src = coeffs + tk.coeff_off;
-    if (!identity) {
-      if (!lossless && ((tk.tx_type & 3) == 0 || bs == 32) && (bs == 4 ? tk.eob <= 1 : tk.eob == 1)) dc_kind = 1;
-      if (lossless && tk.eob <= 1) dc_kind = 2;
-    }
-    if (dc_kind)
-      dc_coeff = src[0];
-    else if (t < bs) {
-      const int rd = identity ? bs : txfm::coeff_rows(tk.eob, lossless ? 0 : (tk.tx_type & 3), bs);
-      for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = i < rd ? src[i * bs + t] : 0;
-    }
+    const int rd = txfm::coeff_rows(tk.eob, lossless ? 0 : tt, N);
+#pragma unroll
+    for (int i = 0; i < N; ++i) pt[i * PITCH + t] = i < rd ? src[i * N + t] : 0;
   }
   slot_sync();
-  if (coded && !dc_kind && !identity && t < bs) {
-    const int tt = tk.tx_type & 3;
-    switch (tk.tx_size) {
-      case 0: row_pass<4, HBD>(tile, t, tt, lossless); break;
-      case 1: row_pass<8, HBD>(tile, t, tt, false); break;
-      case 2: row_pass<16, HBD>(tile, t, tt, false); break;
-      default: row_pass<32, HBD>(tile, t, 0, false); break;
-    }
-  }
+  if (t < N) row_pass<N, HBD, PITCH>(pt, t, N == 32 ? 0 : tt, N == 4 && lossless);
   slot_sync();
-  if (coded) {
-    switch (tk.tx_size) {
-      case 0: residual_block<4, HBD>(tk, t, tile, dc_coeff, dc_kind, rd, f); break;
-      case 1: residual_block<8, HBD>(tk, t, tile, dc_coeff, dc_kind, rd, f); break;
-      case 2: residual_block<16, HBD>(tk, t, tile, dc_coeff, dc_kind, rd, f); break;
-      default: residual_block<32, HBD>(tk, t, tile, dc_coeff, dc_kind, rd, f); break;
-    }
+  if (t < N) {
+    int v[N];
+    col_pass<N, HBD, PITCH>(pt, t, N == 32 ? 0 : tt, N == 4 && lossless, v);
+    const int pl = tk.plane;
+    store_resid_col<N>(&S.tile[S.idx0[pl] + (int)tk.y * S.pitch[pl] + (int)tk.x + t], S.pitch[pl], v);
   }
-  slot_sync();  // the tile is reused by the next chunk of this slot
+  slot_sync();  // the pool tile is reused by the slot's next block
 }
 
-constexpr int RESID_Y = 8;  // workgroups per island: workgroup (i, j) takes chunks j, j + RESID_Y, ... of island i
-template <bool HBD>
-__global__ __launch_bounds__(256) void intra_residual_kernel(const vp9hip_intra_task *__restrict__ tasks,
-                                                             const vp9hip_intra_island *__restrict__ islands,
-                                                             const int32_t *__restrict__ wave_off,
-                                                             const int32_t *__restrict__ coeffs, ResidDev rd, FrameDev f) {
-  __shared__ int tiles[SLOTS][32 * TPITCH];
-  const vp9hip_intra_island isl = islands[blockIdx.x];
-  const int n = wave_off[isl.wave_off_start + isl.n_waves];  // tasks of the island
-  const int slot = threadIdx.x / SLOT;
-  for (int base = blockIdx.y * SLOTS; base < n; base += RESID_Y * SLOTS) {
+// Returns false (workgroup-uniform) when the island does not fit: nothing was written anywhere.
+// sb_done != nullptr: completion marks for the loop filter.
+template <typename Pix, bool HBD>
+__device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra_task *__restrict__ tasks,
+                                                const vp9hip_intra_island &isl, const int32_t *__restrict__ wave_off,
+                                                const int32_t *__restrict__ coeffs, const FrameDev &f,
+                                                int *__restrict__ sb_done, int sb_cols) {
+  const int tid = threadIdx.x;
+  const int32_t *wo = wave_off + isl.wave_off_start;
+  const int nw = (int)isl.n_waves;
+  const int n = wo[nw];
+  if (n > ISL_TASKS) return false;
+  if (tid < 12) S.box[tid >> 2][tid & 3] = (tid & 2) ? 0 : 0x7fffffff;
+  if (tid == 12) S.n32 = S.nmarks = S.bad = 0;
+  __syncthreads();
+  // ---- 1. task records, wave offsets, bounding boxes, the lists of full 32x32 transforms and of completion marks
+  for (int i = tid; i <= nw; i += 256) S.woff[i] = (short)wo[i];  // nw <= n <= ISL_TASKS
+  for (int i = tid; i < n; i += 256) {
+    const vp9hip_intra_task tk = tasks[isl.task_start + i];
+    S.tasks[i] = tk;
+    const int bs = 4 << tk.tx_size, pl = tk.plane < 3 ? tk.plane : 0;
+    atomicMin(&S.box[pl][0], (int)tk.x);
+    atomicMin(&S.box[pl][1], (int)tk.y);
+    atomicMax(&S.box[pl][2], (int)tk.x + bs);
+    atomicMax(&S.box[pl][3], (int)tk.y + bs);
+    if (tk.plane > 2 || tk.tx_size > 3 || (tk.flags & 8)) S.bad = 1;  // (raw edges: the rtcd twins' wave launches only)
+    if (coeffs != nullptr && tk.eob > 0 && tk.tx_size == 3 && resid_kind(tk) == 0) {
+      const int k = atomicAdd(&S.n32, 1);
+      if (k < ISL_TX32) S.list32[k] = (short)i;
+    }
+    if (sb_done != nullptr && (tk.reserved & 1)) {
+      // chroma subsampling from the plane sizes (4:2:0, 4:4:4 or single-plane frames)
+      const int sx = tk.plane && f.awidth[pl] < f.awidth[0], sy = tk.plane && f.aheight[pl] < f.aheight[0];
+      const int k = atomicAdd(&S.nmarks, 1);
+      if (k < ISL_MARKS) S.marks[k] = (((int)tk.y << sy) >> 6) * sb_cols + (((int)tk.x << sx) >> 6);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int p = 0; p < 3; ++p) {
+      const int *b = S.box[p];
+      if (b[2] > b[0]) {
+        const int pitch = VP9HIP_ISLAND_PITCH(b[2] - b[0]);
+        S.pitch[p] = pitch;
+        S.idx0[p] = acc - (b[1] - 1) * pitch - (b[0] - 1);
+        acc += pitch * (b[3] - b[1] + 1);
+      } else {
+        S.pitch[p] = S.idx0[p] = 0;
+      }
+    }
+    if (acc > ISL_TILE || S.n32 > ISL_TX32 || S.nmarks > ISL_MARKS) S.bad = 1;
+  }
+  __syncthreads();
+  if (S.bad) return false;
+  const int wave = tid >> 6, lane = tid & 63;
+  // ---- 2. the window: a wavefront per row
+#pragma unroll 1
+  for (int p = 0; p < 3; ++p) {
+    const int *b = S.box[p];
+    if (b[2] <= b[0]) continue;
+    const int ox = b[0] - 1, oy = b[1] - 1, W = b[2] - b[0] + 5, H = b[3] - b[1] + 1;
+    const int pitch = S.pitch[p], idx0 = S.idx0[p];
+    const Pix *plane = (const Pix *)f.plane[p];
+    const int stride = f.stride[p], fw = f.awidth[p], fh = f.aheight[p];
+    for (int r = wave; r < H; r += 4) {
+      const int gy = oy + r;
+      if (gy < 0 || gy >= fh) continue;
+      for (int c = lane; c < W; c += 64) {
+        const int gx = ox + c;
+        if (gx >= 0 && gx < fw) S.tile[idx0 + gy * pitch + gx] = (short)plane[(size_t)gy * stride + gx];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. residuals: eight blocks at a time (a 32-lane slot each); full 32x32 transforms two at a time
+  const int slot = tid / SLOT, t = tid % SLOT;
+  if (coeffs != nullptr) {
+    for (int base = 0; base < n; base += SLOTS) {
+      const int ti = base + slot;
+      vp9hip_intra_task tk;
+      memset(&tk, 0, sizeof(tk));
+      if (ti < n) tk = S.tasks[ti];
+      const bool coded = ti < n && tk.eob > 0;
+      const int kind = resid_kind(tk);
+      const int bs = 4 << tk.tx_size, pl = tk.plane;
+      int *pt = S.pool + slot * ISL_POOL_SLOT;
+      if (coded && kind != 0) {
+        if (t < bs) {
+          short *dst = &S.tile[S.idx0[pl] + (int)tk.y * S.pitch[pl] + (int)tk.x + t];
+          const int32_t *src = coeffs + tk.coeff_off;
+          const int pitch = S.pitch[pl];
+          if (kind == 3) {
+            for (int k = 0; k < bs; ++k) dst[k * pitch] = sat16(src[k * bs + t]);
+          } else if (kind == 1) {
+            const short a1 = sat16(dc_only_shift<HBD>(src[0], tk.tx_size == 0 ? 4 : (tk.tx_size == 1 ? 5 : 6)));
+            for (int k = 0; k < bs; ++k) dst[k * pitch] = a1;
+          } else {  // vpx_iwht4x4_1_add_c (inv_txfm.c:71-94)
+            txfm::i64 a1 = src[0] >> 2, e1 = a1 >> 1;
+            a1 -= e1;
+            const int ip = t == 0 ? (int)a1 : (int)e1;
+            const int e = ip >> 1;
+            dst[0] = sat16(ip - e);
+            dst[pitch] = dst[2 * pitch] = dst[3 * pitch] = sat16(e);
+          }
+        }
+      }
+      // (a wavefront holds two slots: the transforms of both run under one uniform switch per size)
+      const bool full = coded && kind == 0;
+      if (__builtin_amdgcn_ballot_w64(full && tk.tx_size == 0)) {
+        if (full && tk.tx_size == 0) island_full_transform<4, HBD, ISL_POOL_PITCH>(S, tk, t, pt, coeffs);
+      }
+      if (__builtin_amdgcn_ballot_w64(full && tk.tx_size == 1)) {
+        if (full && tk.tx_size == 1) island_full_transform<8, HBD, ISL_POOL_PITCH>(S, tk, t, pt, coeffs);
+      }
+      if (__builtin_amdgcn_ballot_w64(full && tk.tx_size == 2)) {
+        if (full && tk.tx_size == 2) island_full_transform<16, HBD, ISL_POOL_PITCH>(S, tk, t, pt, coeffs);
+      }
+    }
+    const int n32 = S.n32;
+    if (n32) __syncthreads();  // the two big tiles lie over the eight small ones
+    for (int j = 0; j < n32; j += 2) {
+      // wavefronts 0 and 2, lanes 0..31: one 32x33 pool tile each
+      const int q = wave >> 1;
+      if ((wave & 1) == 0 && j + q < n32 && lane < 32)
+        island_full_transform<32, HBD, 33>(S, S.tasks[S.list32[j + q]], lane, S.pool + q * (ISL_POOL_INTS / 2), coeffs);
+    }
+  }
+  __syncthreads();
+  // ---- 4. the waves.  Task j of a chunk goes to wavefront j % 4 (slot 2 * (j % 4) + j / 4): most waves of a deep
+  // chain have four tasks or fewer, and the two slots of a wavefront run one after the other where they differ
+  const int wslot = ((tid / SLOT) & 1) * (SLOTS / 2) + (tid / SLOT) / 2;
+  const int maxv = (1 << f.bit_depth) - 1;
+  const int basev = 128 << (f.bit_depth - 8);
+  int *E = S.edge[wslot] + EOFF;
+  for (int w = 0; w < nw; ++w) {
+    const int begin = S.woff[w], end = S.woff[w + 1];
+    for (int base = begin; base < end; base += SLOTS) {
+      const int ti = base + wslot;
+      const bool active = ti < end;
+      vp9hip_intra_task tk;
+      memset(&tk, 0, sizeof(tk));
+      if (active) tk = S.tasks[ti];
+      const int bs = 4 << tk.tx_size, lg = 2 + tk.tx_size, pl = tk.plane;
+      const int pitch = S.pitch[pl], idx0 = S.idx0[pl];
+      const int x = tk.x, y = tk.y;
+      const bool have_top = tk.flags & 1, have_left = (tk.flags >> 1) & 1, have_right = (tk.flags >> 2) & 1;
+      int dc = 0;
+      if (active) {
+        const int fw = f.awidth[pl], fh = f.aheight[pl];
+        // above: entries 0..2bs-1 (+ above-left); the rules of intra_chunk (vp9_reconintra.c:322-393)
+        int take;
+        const bool ext = bs == 4 && have_right;
+        if (x + 2 * bs <= fw)
+          take = ext ? 2 * bs : bs;
+        else if (x + bs <= fw)
+          take = ext ? fw - x : bs;
+        else
+          take = fw - x;
+        int part = 0;
+        const short *arow = &S.tile[idx0 + (y - 1) * pitch + x];
+        for (int i = t; i < 2 * bs; i += SLOT) {
+          const int v = have_top ? (int)arow[i < take ? i : take - 1] : basev - 1;
+          E[1 + i] = v;
+          if (have_top && i < bs) part += v;
+        }
+        if (t == 0) E[0] = have_top ? (have_left ? (int)arow[-1] : basev + 1) : basev - 1;
+        const int valid = (y + bs <= fh) ? bs : fh - y;
+        if (t < bs) {
+          const int v = have_left ? (int)S.tile[idx0 + (y + (t < valid ? t : valid - 1)) * pitch + x - 1] : basev + 1;
+          E[-1 - t] = v;
+          if (have_left) part += v;
+        }
+        if (tk.mode == 0) {  // dc_pred[left][up] (vp9_reconintra.c:86-89): rounded mean of what is there
+          const int sum = slot_sum32(part);
+          const int lcnt = lg + (have_top && have_left ? 1 : 0);
+          dc = (have_top || have_left) ? (sum + ((1 << lcnt) >> 1)) >> lcnt : basev;
+        }
+      }
+      slot_sync();
+      if (active) {
+        const bool coded = coeffs != nullptr && tk.eob > 0;
+        short *blk = &S.tile[idx0 + y * pitch + x];
+        for (int i = t; i < bs * bs; i += SLOT) {
+          const int r = i >> lg, c = i & (bs - 1);
+          int px = predict_px(tk.mode, bs, r, c, E, dc, maxv);
+          short *d = blk + r * pitch + c;
+          if (coded) px = clip_to(px + (int)*d, maxv);
+          *d = (short)px;
+        }
+      }
+      slot_sync();  // E is rewritten by the slot's next block
+    }
+    __syncthreads();
+  }
+  // ---- 5. the island's blocks -> the frame: four samples per lane and store
+  for (int base = 0; base < n; base += SLOTS) {
     const int ti = base + slot;
-    residual_chunk<HBD>(tiles, tasks, isl.task_start + ti, ti < n, coeffs, rd, f);
-  }
-}
-
-template <typename Pix>
-__device__ __forceinline__ void intra_chunk_res(int (*edge)[ESIZE], const vp9hip_intra_task *__restrict__ tasks, int index,
-                                                bool active, const ResidDev &rd, const FrameDev &f) {
-  const int slot = threadIdx.x / SLOT, t = threadIdx.x % SLOT;
-  vp9hip_intra_task tk;
-  memset(&tk, 0, sizeof(tk));
-  if (active) tk = tasks[index];
-  const int bs = 4 << tk.tx_size;
-  const int pl = tk.plane;
-  const bool coded = active && rd.p != nullptr && tk.eob > 0;
-  int *E = edge[slot] + EOFF;
-  // residual column of this lane: independent of the neighbours, so for the small blocks (the bulk of a
-  // deep chain) the loads go out before the edge loads; 16x16 / 32x32 columns are loaded where they
-  // are used (32 more live registers across the edge assembly would be parked in AGPRs)
-  int v4[4], v8[8];
-  const bool has_col = coded && t < bs && (int)tk.x + t < f.awidth[pl];
-  const int *rp = rd.p + rd.off[pl] + (size_t)tk.y * rd.stride[pl] + tk.x + t;
-  const int rs = rd.stride[pl];
-  const int rrows = min(bs, f.aheight[pl] - (int)tk.y);
-  if (has_col) {
-    if (tk.tx_size == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v4[k] = k < rrows ? rp[(size_t)k * rs] : 0;
-    } else if (tk.tx_size == 1) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v8[k] = k < rrows ? rp[(size_t)k * rs] : 0;
-    }
-  }
-  if (active) {
-    const Pix *plane = (const Pix *)f.plane[pl];
-    const int stride = f.stride[pl];
-    const int fw = f.awidth[pl], fh = f.aheight[pl];
-    const int base = 128 << (f.bit_depth - 8);
-    const bool have_top = tk.flags & 1, have_left = (tk.flags >> 1) & 1, have_right = (tk.flags >> 2) & 1;
-    const int x = tk.x, y = tk.y;
-    {  // above row (same rules as intra_chunk)
-      int take;
-      const bool ext = (bs == 4 && have_right) || (tk.flags & 8);
-      if (x + 2 * bs <= fw)
-        take = ext ? 2 * bs : bs;
-      else if (x + bs <= fw)
-        take = ext ? fw - x : bs;
-      else
-        take = fw - x;
-      for (int i = t; i < 2 * bs; i += SLOT) {
-        int e;
-        if (have_top)
-          e = plane[(size_t)(y - 1) * stride + x + (i < take ? i : take - 1)];
-        else
-          e = base - 1;
-        E[1 + i] = e;
-      }
-      if (t == 0) E[0] = have_top ? (have_left ? (int)plane[(size_t)(y - 1) * stride + x - 1] : base + 1) : base - 1;
-    }
-    {
-      const int valid = (y + bs <= fh) ? bs : fh - y;
-      for (int i = t; i < bs; i += SLOT) {
-        int e;
-        if (have_left)
-          e = plane[(size_t)(y + (i < valid ? i : valid - 1)) * stride + x - 1];
-        else
-          e = base + 1;
-        E[-1 - i] = e;
+    if (ti >= n) continue;
+    const vp9hip_intra_task tk = S.tasks[ti];
+    const int bs = 4 << tk.tx_size, lgq = tk.tx_size, pl = tk.plane;  // bs / 4 pieces per row
+    const int pitch = S.pitch[pl];
+    const short *blk = &S.tile[S.idx0[pl] + (int)tk.y * pitch + (int)tk.x];
+    Pix *dst = (Pix *)f.plane[pl] + (size_t)tk.y * f.stride[pl] + tk.x;
+    const int rows = min(bs, f.aheight[pl] - (int)tk.y), cols = min(bs, f.awidth[pl] - (int)tk.x);  // multiples of 4
+    for (int i = t; i < (bs * bs) >> 2; i += SLOT) {
+      const int r = i >> lgq, c = (i & ((1 << lgq) - 1)) * 4;
+      if (r >= rows || c >= cols) continue;
+      const short *sp = blk + r * pitch + c;
+      if constexpr (sizeof(Pix) == 1) {
+        const unsigned v = (unsigned)sp[0] | ((unsigned)sp[1] << 8) | ((unsigned)sp[2] << 16) | ((unsigned)sp[3] << 24);
+        *(unsigned *)(dst + (size_t)r * f.stride[pl] + c) = v;
+      } else {
+        uint2 v;
+        v.x = (unsigned)(unsigned short)sp[0] | ((unsigned)(unsigned short)sp[1] << 16);
+        v.y = (unsigned)(unsigned short)sp[2] | ((unsigned)(unsigned short)sp[3] << 16);
+        *(uint2 *)(dst + (size_t)r * f.stride[pl] + c) = v;
       }
     }
   }
-  slot_sync();
-  if (active) {
-    switch (tk.tx_size) {
-      case 0: finish_block_res<4, Pix>(tk, t, E, v4, coded, f); break;
-      case 1: finish_block_res<8, Pix>(tk, t, E, v8, coded, f); break;
-      case 2: {
-        int v16[16];
-        if (has_col) {
-#pragma unroll
-          for (int k = 0; k < 16; ++k) v16[k] = k < rrows ? rp[(size_t)k * rs] : 0;
-        }
-        finish_block_res<16, Pix>(tk, t, E, v16, coded, f);
-        break;
-      }
-      default: {
-        int v32[32];
-        if (has_col) {
-#pragma unroll
-          for (int k = 0; k < 32; ++k) v32[k] = k < rrows ? rp[(size_t)k * rs] : 0;
-        }
-        finish_block_res<32, Pix>(tk, t, E, v32, coded, f);
-        break;
-      }
+  if (sb_done != nullptr) {
+    // Completion marks.  Producer half of the hand-off recipe (MI355X_MICROARCH.md, "Valid forms"): plain stores,
+    // every storing wave's vmcnt(0) + the barrier (__syncthreads), ONE agent-scope release (writes this XCD's dirty
+    // L2 lines back), waited for, then the counters; the filter polls them and acquires (lf_kernels.hip, gate_col).
+    __syncthreads();
+    if (wave == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int k = lane; k < S.nmarks; k += 64)
+        __hip_atomic_fetch_add(&sb_done[S.marks[k]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  slot_sync();  // E is rewritten by the next chunk of this slot
+  return true;
 }
 
 // One launch per dependency wave of the whole frame (deep structures: key frames).
@@ -572,201 +756,48 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task
   intra_chunk<Pix, HBD>(edge, tiles, tasks, first + ti, ti < count, coeffs, f);
 }
 
-// One workgroup per ISLAND (connected component of the intra dependency graph, e.g. an intra
-// superblock inside an inter frame): it walks the island's waves in order, 8 blocks at a time,
-// with a workgroup barrier between waves — no kernel boundary, no inter-workgroup traffic.
-// __syncthreads() orders the global stores of one wave before the edge loads of the next for
-// the threads of this workgroup (same CU, same L1).
-template <typename Pix, bool HBD, bool RES>
-__device__ __forceinline__ void intra_island_body(const vp9hip_intra_task *__restrict__ tasks,
-                                                  const vp9hip_intra_island *__restrict__ islands,
-                                                  const int32_t *__restrict__ wave_off, const int32_t *__restrict__ coeffs,
-                                                  const ResidDev &rd, const FrameDev &f, int *__restrict__ sb_done, int sb_cols,
-                                                  int island) {
-  __shared__ int edge[SLOTS][ESIZE];
-  __shared__ int tiles[RES ? 1 : SLOTS][RES ? 1 : 32 * TPITCH];
-  const vp9hip_intra_island isl = islands[island];
-  // The two slots of a wavefront run their blocks one after the other wherever the blocks differ (size,
-  // mode), and most waves of a deep chain have four tasks or fewer: task j of a chunk goes to wavefront
-  // j % 4 (slot 2 * (j % 4) + j / 4), so that up to four tasks get a wavefront each.  With slot = task the
-  // first wavefront carried two blocks in every wave (4800 cycles per wave against 3100 / 1400 / 700 for
-  // the other three, in-kernel stamps on the deepest island of the bench frame).
+// One workgroup per island, walked through the frame in memory: the island's waves in order, 8 blocks at a time,
+// with a workgroup barrier between waves.  __syncthreads() orders the global stores of one wave before the edge
+// loads of the next for the threads of this workgroup (same CU, same L1).  For islands that do not fit the LDS
+// window.
+template <typename Pix, bool HBD>
+__device__ __forceinline__ void island_mem_body(IslandMemLds &M, const vp9hip_intra_task *__restrict__ tasks,
+                                                const vp9hip_intra_island &isl, const int32_t *__restrict__ wave_off,
+                                                const int32_t *__restrict__ coeffs, const FrameDev &f) {
+  // task j of a chunk goes to wavefront j % 4 (see island_lds_body)
   const int slot = ((threadIdx.x / SLOT) & 1) * (SLOTS / 2) + (threadIdx.x / SLOT) / 2;
-  // the offsets of a wave are fetched a wave ahead (a scalar load, waited for only when they are used)
   const int32_t *wo = wave_off + isl.wave_off_start;
   const int nw = (int)isl.n_waves;
-  int begin = wo[0], end = wo[nw > 0 ? 1 : 0];
   for (int w = 0; w < nw; ++w) {
-    const int nend = wo[w + 2 <= nw ? w + 2 : nw];
+    const int begin = wo[w], end = wo[w + 1];
     for (int base = begin; base < end; base += SLOTS) {
       const int ti = base + slot;
-      if constexpr (RES)
-        intra_chunk_res<Pix>(edge, tasks, isl.task_start + ti, ti < end, rd, f);
-      else
-        intra_chunk<Pix, HBD>(edge, (int (*)[32 * TPITCH])tiles, tasks, isl.task_start + ti, ti < end, coeffs, f);
+      intra_chunk<Pix, HBD>(M.edge, M.tiles, tasks, isl.task_start + ti, ti < end, coeffs, f);
     }
     __syncthreads();
-    // Overlap with the loop filter (vp9hip_intra_islands_lf): a task with bit 0 of `reserved` set is the
-    // LAST task of this island inside its luma superblock (the packer marks it); once its wave is done,
-    // everything this island does inside that superblock is done, and the superblock's counter goes up —
-    // the loop filter follows the walk superblock by superblock instead of waiting for whole islands
-    // (the deepest one runs for ~60 waves).  Every wave's stores are complete (the __syncthreads above
-    // drains vmcnt and joins the waves); an agent-scope release writes this XCD's dirty L2 lines back
-    // before the counter moves: the producer half of the hand-off recipe of MI355X_MICROARCH.md.
-    // (Write-through stores instead of the fence were measured: they put the memory round trip into
-    // every wave of the chain, 240 -> 384 us for the walk.)
-    if (sb_done != nullptr) {
-      for (int ti = begin + (int)threadIdx.x; ti < end; ti += (int)blockDim.x) {
-        const vp9hip_intra_task tk = tasks[isl.task_start + ti];
-        if (tk.reserved & 1) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          // chroma subsampling from the plane sizes (the overlapped call takes 4:2:0 or single-plane frames)
-          const int sx = tk.plane && f.awidth[tk.plane] < f.awidth[0], sy = tk.plane && f.aheight[tk.plane] < f.aheight[0];
-          const int sb = (((int)tk.y << sy) >> 6) * sb_cols + (((int)tk.x << sx) >> 6);
-          __hip_atomic_fetch_add(&sb_done[sb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-    begin = end;
-    end = nend;
   }
 }
 
-template <typename Pix, bool HBD, bool RES>
+union IslandAnyLds {
+  IslandLds lds;
+  IslandMemLds mem;
+};
+
+template <typename Pix, bool HBD>
 __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_task *__restrict__ tasks,
                                                            const vp9hip_intra_island *__restrict__ islands,
                                                            const int32_t *__restrict__ wave_off,
-                                                           const int32_t *__restrict__ coeffs, ResidDev rd, FrameDev f,
-                                                           int *__restrict__ sb_done, int sb_cols) {
-  intra_island_body<Pix, HBD, RES>(tasks, islands, wave_off, coeffs, rd, f, sb_done, sb_cols, (int)blockIdx.x);
+                                                           const int32_t *__restrict__ coeffs, FrameDev f) {
+  __shared__ IslandAnyLds S;
+  const vp9hip_intra_island isl = islands[blockIdx.x];
+  if (island_lds_body<Pix, HBD>(S.lds, tasks, isl, wave_off, coeffs, f, nullptr, 0)) return;
+  __syncthreads();
+  island_mem_body<Pix, HBD>(S.mem, tasks, isl, wave_off, coeffs, f);
 }
 
 }  // namespace
 
 #ifndef VP9HIP_INTRA_DEVICE_ONLY  // lf_kernels.hip includes this file for the device code above (fused walk + filter)
-// Residual scratch of the context: one int32 per sample of the frame, planes back to back.  Growing it
-// synchronises, so callers that fork streams make sure of it first.
-int vp9hip_ensure_resid(vp9hip_ctx *ctx, const vp9hip_frame *frame) {
-  size_t need = 0;
-  for (int pl = 0; pl < 3; ++pl)
-    if (frame->plane[pl]) need += (size_t)frame->awidth[pl] * frame->aheight[pl] * sizeof(int);
-  if (need <= ctx->resid_bytes) return VP9HIP_OK;
-  if (ctx->resid) VP9HIP_CHECK(ctx, hipFree(ctx->resid));
-  ctx->resid = nullptr;
-  ctx->resid_bytes = 0;
-  VP9HIP_CHECK(ctx, hipMalloc(&ctx->resid, need));
-  ctx->resid_bytes = need;
-  return VP9HIP_OK;
-}
-
-#endif  // !VP9HIP_INTRA_DEVICE_ONLY
-
-static ResidDev resid_dev(vp9hip_ctx *ctx, const vp9hip_frame *frame) {
-  ResidDev rd;
-  memset(&rd, 0, sizeof(rd));
-  rd.p = (int *)ctx->resid;
-  int acc = 0;
-  for (int pl = 0; pl < 3; ++pl) {
-    rd.off[pl] = acc;
-    rd.stride[pl] = frame->awidth[pl];
-    if (frame->plane[pl]) acc += frame->awidth[pl] * frame->aheight[pl];
-  }
-  return rd;
-}
-
-#ifndef VP9HIP_INTRA_DEVICE_ONLY
-
-static int residual_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
-                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
-                           const int32_t *d_coeffs, const vp9hip_frame *frame) {
-  const FrameDev f = to_dev(frame);
-  const ResidDev rd = resid_dev(ctx, frame);
-  if (frame->hbd)
-    hipLaunchKernelGGL((intra_residual_kernel<true>), dim3(n_islands, RESID_Y), dim3(256), 0, st, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, rd, f);
-  else
-    hipLaunchKernelGGL((intra_residual_kernel<false>), dim3(n_islands, RESID_Y), dim3(256), 0, st, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, rd, f);
-  VP9HIP_CHECK(ctx, hipGetLastError());
-  return VP9HIP_OK;
-}
-
-// Optional head start (include/vp9hip.h): the pre-pass reads the lists and the coefficients only, so it
-// can run beside the frame's convolve and transforms.  It goes to the context's second stream, ordered
-// after everything enqueued so far (the uploads of its inputs); the island launch of the same lists
-// waits for it instead of running it.
-extern "C" int vp9hip_intra_residual_begin(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
-                                           const vp9hip_intra_island *d_islands, int n_islands,
-                                           const int32_t *d_wave_off, const int32_t *d_coeffs,
-                                           const vp9hip_frame *frame) {
-  if (!ctx) return VP9HIP_EINVAL;
-  VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !frame_ok(frame))
-    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_residual_begin: bad argument");
-  ctx->resid_tasks = nullptr;
-  if (n_islands == 0 || !d_coeffs) return VP9HIP_OK;
-  int rc = vp9hip_ensure_resid(ctx, frame);
-  if (rc) return rc;
-  if (!ctx->stream2) VP9HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-  if (!ctx->ev_resid_start) {
-    VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_resid_start, hipEventDisableTiming));
-    VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_resid_done, hipEventDisableTiming));
-  }
-  VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_resid_start, ctx->stream));
-  VP9HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_resid_start, 0));
-  // the zero-fill of the filter / island counters of vp9hip_intra_islands_lf rides along (4:2:0 or luma only)
-  ctx->lf_zeroed_rows = ctx->lf_zeroed_cols = 0;
-  if (frame->aheight[0] <= 128 * 64 && frame->awidth[0] <= 128 * 64) {
-    rc = vp9hip_lf_zero_counters(ctx, frame, ctx->stream2);
-    if (rc) return rc;
-  }
-  rc = residual_launch(ctx, ctx->stream2, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
-  if (rc) return rc;
-  VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_resid_done, ctx->stream2));
-  ctx->resid_tasks = d_tasks;
-  ctx->resid_coeffs = d_coeffs;
-  return VP9HIP_OK;
-}
-
-// The residual of the island tasks on stream `st`: the pre-pass vp9hip_intra_residual_begin started for these
-// lists is waited for, or it is run now.  After this the island walk of the lists may be enqueued on `st`.
-int vp9hip_islands_prepare(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
-                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
-                           const int32_t *d_coeffs, const vp9hip_frame *frame) {
-  if (d_coeffs) {
-    // the inverse transforms of every coded task, in parallel, ahead of the dependent walk
-    int rc = vp9hip_ensure_resid(ctx, frame);
-    if (rc) return rc;
-    if (ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs) {
-      VP9HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_resid_done, 0));  // vp9hip_intra_residual_begin did it
-    } else {
-      rc = residual_launch(ctx, st, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
-      if (rc) return rc;
-    }
-  }
-  ctx->resid_tasks = nullptr;
-  return VP9HIP_OK;
-}
-
-int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
-                          const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
-                          const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_sb_done, int sb_cols) {
-  const FrameDev f = to_dev(frame);
-  ResidDev rd;
-  memset(&rd, 0, sizeof(rd));
-  int rc = vp9hip_islands_prepare(ctx, st, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
-  if (rc) return rc;
-  if (d_coeffs) rd = resid_dev(ctx, frame);
-  if (frame->hbd)
-    hipLaunchKernelGGL((intra_island_kernel<uint16_t, true, true>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);
-  else
-    hipLaunchKernelGGL((intra_island_kernel<uint8_t, false, true>), dim3(n_islands), dim3(256), 0, st, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, rd, f, d_sb_done, sb_cols);
-  VP9HIP_CHECK(ctx, hipGetLastError());
-  return VP9HIP_OK;
-}
-
 extern "C" int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
                                          const vp9hip_intra_island *d_islands, int n_islands,
                                          const int32_t *d_wave_off, const int32_t *d_coeffs,
@@ -776,7 +807,15 @@ extern "C" int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_tas
   if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !frame_ok(frame))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_islands: bad argument");
   if (n_islands == 0) return VP9HIP_OK;
-  return vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, nullptr, 0);
+  const FrameDev f = to_dev(frame);
+  if (frame->hbd)
+    hipLaunchKernelGGL((intra_island_kernel<uint16_t, true>), dim3(n_islands), dim3(256), 0, ctx->stream, d_tasks, d_islands,
+                       d_wave_off, d_coeffs, f);
+  else
+    hipLaunchKernelGGL((intra_island_kernel<uint8_t, false>), dim3(n_islands), dim3(256), 0, ctx->stream, d_tasks, d_islands,
+                       d_wave_off, d_coeffs, f);
+  VP9HIP_CHECK(ctx, hipGetLastError());
+  return VP9HIP_OK;
 }
 
 extern "C" int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks, const int32_t *wave_start,

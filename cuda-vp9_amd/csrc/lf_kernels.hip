@@ -5,9 +5,8 @@
 // columns [64c-8, 64c+63] (vertical pass, rows of SB row r) and rows [64r-8, 64r+63]
 // (horizontal pass, columns of SB column c), so it must run after (r,c-1) and (r-1,c+1) —
 // libvpx's own row-MT sync rule (vp9_thread_common.c:38-55).  All superblocks with the same
-// t = c + 2r are independent: the first form here (lf_diag_kernel, VP9HIP_LF_MODE=diag) is one launch
-// per anti-diagonal t, one wavefront per (superblock, plane); the default is the row walk further
-// down (lf_rows2_kernel): one launch, a workgroup per (superblock row, plane), rows pipelined.
+// t = c + 2r are independent; here ONE launch walks the rows (lf_rows2_kernel): a workgroup per
+// (superblock row, plane), rows pipelined behind each other.
 //
 // Inside a superblock plane the 64 (32) pixel rows are independent in the vertical pass and
 // the 64 (32) columns in the horizontal pass: lane = row, then lane = column.  Each lane walks
@@ -198,17 +197,6 @@ __device__ __forceinline__ void lf_controls(unsigned *ctl, const vp9hip_lfm &m, 
   }
 }
 
-// ---- the two passes over a staged tile ------------------------------------------------------------
-// WG_SYNC: the tile is shared by the whole workgroup (barriers) or owned by ONE wave (then LDS is
-// in-order for that wave and a fence that drains lgkmcnt and pins the compiler is enough).
-template <bool WG_SYNC>
-__device__ __forceinline__ void lf_tile_sync() {
-  if constexpr (WG_SYNC)
-    __syncthreads();
-  else
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-}
-
 // ---- vertical edges: lane = sample row; a 16-sample window slides along the row
 template <typename Pix, int N>
 __device__ __forceinline__ void lf_pass_v(Pix *tile, const unsigned *ctl, int y0, int ph, int mrows, int sh,
@@ -294,90 +282,6 @@ __device__ __forceinline__ void lf_pass_h(Pix *tile, const unsigned *ctl, int x0
   }
 }
 
-template <typename Pix, int N, bool WG_SYNC = true>
-__device__ __forceinline__ void lf_passes(Pix *tile, const unsigned *ctl, int x0, int y0, int pw, int ph, int mrows,
-                                          int sh) {
-  lf_pass_v<Pix, N>(tile, ctl, y0, ph, mrows, sh);
-  lf_tile_sync<WG_SYNC>();
-  lf_pass_h<Pix, N>(tile, ctl, x0, pw, mrows, sh);
-  lf_tile_sync<WG_SYNC>();
-}
-
-// One (superblock, plane): N = 64 (luma) or 32 (4:2:0 chroma) samples per side.
-// ctl: 4 x 64 dwords of LDS: per mask bit the packed (kind << 24 | hev << 16 | lim << 8 | mblim)
-// of the block-edge filter and of the interior 4x4 filter, for the vertical and horizontal pass.
-template <typename Pix, int N>
-__device__ __forceinline__ void lf_sb_body(Pix *tile, unsigned *ctl, const vp9hip_lfm &m, int sr, int sc, int pl,
-                                           const LfThreshDev &th, const FrameDev &f, int mi_rows) {
-  constexpr int TP = TileCfg<Pix>::TP;
-  constexpr int PPD = 4 / sizeof(Pix);  // samples per dword
-  const int lane = threadIdx.x;
-  const int sh = sizeof(Pix) == 1 ? 0 : f.bit_depth - 8;  // 8-bit samples: a constant, so the clamps fold to v_med3
-  constexpr int n = N;         // samples per superblock side in this plane
-  constexpr int ncol = N / 8;  // mask columns per mask row
-  const int x0 = sc * n, y0 = sr * n;
-  Pix *plane = (Pix *)f.plane[pl];
-  const int stride = f.stride[pl];
-  const int pw = f.awidth[pl], ph = f.aheight[pl];
-  const int mi_row = sr * 8;
-  const int rows_mi = min(8, mi_rows - mi_row);
-  const int mrows = N == 32 ? ((rows_mi + 1) >> 1) : rows_mi;  // mask rows of this plane
-  // ---- stage the tile: rows y0-8 .. y0+n-1, cols x0-8 .. x0+n-1 (clipped), dword accesses,
-  // all loads issued before the first LDS store
-  constexpr int tw = n + 8;      // samples per tile row
-  constexpr int dpr = tw / PPD;  // dwords per tile row
-  constexpr int total = dpr * tw;
-  constexpr int K = (total + 63) / 64;
-  unsigned *tile32 = (unsigned *)tile;
-  constexpr int TPD = TP / PPD;  // LDS pitch in dwords
-  unsigned stage[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int i = lane + 64 * k;
-    const int r = i / dpr, d = i - r * dpr;
-    const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
-    stage[k] = 0;
-    if (i < total && gx >= 0 && gy >= 0 && gx < pw && gy < ph)
-      stage[k] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
-  }
-
-  lf_controls<N>(ctl, m, pl, mi_row, rows_mi, mi_rows, th);
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int i = lane + 64 * k;
-    const int r = i / dpr, d = i - r * dpr;
-    if (i < total) tile32[r * TPD + d] = stage[k];
-  }
-  __syncthreads();
-
-  lf_passes<Pix, N>(tile, ctl, x0, y0, pw, ph, mrows, sh);
-
-  // write the tile back (the top-left 8x8 corner belongs to nobody here)
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int i = lane + 64 * k;
-    const int r = i / dpr, d = i - r * dpr;
-    const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
-    if (i < total && !(r < 8 && d * PPD < 8) && gx >= 0 && gy >= 0 && gx < pw && gy < ph)
-      *(unsigned *)(plane + (size_t)gy * stride + gx) = tile32[r * TPD + d];
-  }
-}
-
-template <typename Pix>
-__global__ __launch_bounds__(64) void lf_diag_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int t,
-                                                     int r_min, LfThreshDev th, FrameDev f, int mi_rows) {
-  __shared__ __attribute__((aligned(16))) Pix tile[72 * TileCfg<Pix>::TP];
-  __shared__ unsigned ctl[256];
-  const int sr = r_min + blockIdx.x, sc = t - 2 * sr;
-  const int pl = blockIdx.y;
-  const vp9hip_lfm &m = lfms[sr * sb_cols + sc];
-  if (pl == 0 || f.awidth[pl] == f.awidth[0])
-    lf_sb_body<Pix, 64>(tile, ctl, m, sr, sc, pl, th, f, mi_rows);
-  else
-    lf_sb_body<Pix, 32>(tile, ctl, m, sr, sc, pl, th, f, mi_rows);
-}
-
-
 // =============================================================================================
 // Row-walking form: ONE launch.  Workgroup (r, plane) owns superblock row r and walks it left to
 // right, which is the order the vertical-edge chain imposes anyway; it may start superblock c
@@ -394,6 +298,7 @@ __global__ __launch_bounds__(64) void lf_diag_kernel(const vp9hip_lfm *__restric
 // for the duration of the launch (plain loads/stores).  All sb_rows x planes workgroups are
 // co-resident (69 at 1440p), and row r only ever waits on row r-1, so there is no cycle.
 // The left 8 columns of a tile never leave LDS between two superblocks of a row.
+// Every wait is bounded all the same: a row that gives up raises the context's error flag (vp9hip_sync reports it).
 constexpr int LF_SPIN_LIMIT = 1 << 18;  // x (s_sleep + L2 round trip) ~ a fraction of a second, then give up
 
 __device__ __forceinline__ unsigned ld_sc1(const unsigned *p) {
@@ -415,114 +320,6 @@ __device__ __forceinline__ void st_granule(lf_granule *p, unsigned data, unsigne
   __hip_atomic_store(p, ((lf_granule)tag << 32) | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename Pix, int N>
-__device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9hip_lfm *__restrict__ lfms, int sb_cols,
-                                            int sr, int pl, const LfThreshDev &th, const FrameDev &f, int mi_rows,
-                                            int *progress_prev, int *progress_mine, int *err) {
-  constexpr int TP = TileCfg<Pix>::TP;
-  constexpr int PPD = 4 / sizeof(Pix);
-  constexpr int n = N;
-  constexpr int TPD = TP / PPD;
-  constexpr int DPR = n / PPD;                 // dwords per interior row
-  constexpr int KI = (n * DPR + 63) / 64;      // interior dwords per lane
-  constexpr int KA = (8 * DPR + 63) / 64;      // above-row dwords per lane
-  const int lane = threadIdx.x;
-  const int sh = sizeof(Pix) == 1 ? 0 : f.bit_depth - 8;  // 8-bit samples: a constant, so the clamps fold to v_med3
-  Pix *plane = (Pix *)f.plane[pl];
-  const int stride = f.stride[pl];
-  const int pw = f.awidth[pl], ph = f.aheight[pl];
-  const int y0 = sr * n;
-  const int mi_row = sr * 8;
-  const int rows_mi = min(8, mi_rows - mi_row);
-  const int mrows = N == 32 ? ((rows_mi + 1) >> 1) : rows_mi;
-  unsigned *tile32 = (unsigned *)tile;
-
-  bool dead = false;  // a wait timed out: stop waiting (the error flag is set), just finish
-  for (int sc = 0; sc < sb_cols; ++sc) {
-    const int x0 = sc * n;
-    // interior of this superblock: rows y0.., cols x0..  (private to this workgroup: plain loads)
-    unsigned reg[KI];
-#pragma unroll
-    for (int k = 0; k < KI; ++k) {
-      const int i = lane + 64 * k;
-      const int r = i / DPR, d = i - r * DPR;
-      const int gx = x0 + d * PPD, gy = y0 + r;
-      reg[k] = 0;
-      if (i < n * DPR && gx < pw && gy < ph) reg[k] = *(const unsigned *)(plane + (size_t)gy * stride + gx);
-    }
-    lf_controls<N>(ctl, lfms[sr * sb_cols + sc], pl, mi_row, rows_mi, mi_rows, th);
-    // rows above: produced by row sr-1, handed off through its progress counter
-    unsigned above[KA];
-#pragma unroll
-    for (int k = 0; k < KA; ++k) above[k] = 0;
-    if (sr > 0) {
-      const int need = min(sc + 2, sb_cols);
-      int spins = 0;
-      while (!dead && __hip_atomic_load(progress_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > LF_SPIN_LIMIT) {
-          if (lane == 0) atomicExch(err, 1);
-          dead = true;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int k = 0; k < KA; ++k) {
-        const int i = lane + 64 * k;
-        const int r = i / DPR, d = i - r * DPR;
-        const int gx = x0 + d * PPD, gy = y0 - 8 + r;
-        if (i < 8 * DPR && gx < pw) above[k] = ld_sc1((const unsigned *)(plane + (size_t)gy * stride + gx));
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < KI; ++k) {
-      const int i = lane + 64 * k;
-      const int r = i / DPR, d = i - r * DPR;
-      if (i < n * DPR) tile32[(8 + r) * TPD + 8 / PPD + d] = reg[k];
-    }
-#pragma unroll
-    for (int k = 0; k < KA; ++k) {
-      const int i = lane + 64 * k;
-      const int r = i / DPR, d = i - r * DPR;
-      if (i < 8 * DPR) tile32[r * TPD + 8 / PPD + d] = above[k];
-    }
-    __syncthreads();
-    lf_passes<Pix, N>(tile, ctl, x0, y0, pw, ph, mrows, sh);
-    // ---- write back.  Final now: tile columns [0, n) (+ the right strip for the last superblock
-    // of the row), rows above included.  The bottom 8 rows go out write-through (handed to row sr+1).
-    const bool last = (sc == sb_cols - 1) || (x0 + n >= pw);
-    const int wcols = last ? n + 8 : n;  // tile columns of the superblock rows that are final now
-    constexpr int wd = (n + 8) / PPD;
-    for (int i = lane; i < (n + 8) * wd; i += 64) {
-      const int r = i / wd, d = i - r * wd;
-      const int gx = x0 - 8 + d * PPD, gy = y0 - 8 + r;
-      // rows above: this superblock's own columns (tile columns 8 .. n+7); superblock rows: tile
-      // columns 0 .. wcols-1 (the right strip stays in LDS for the next superblock)
-      if (r < 8 ? (d * PPD < 8) : (d * PPD >= wcols)) continue;
-      if (gx < 0 || gy < 0 || gx >= pw || gy >= ph) continue;
-      unsigned *gp = (unsigned *)(plane + (size_t)gy * stride + gx);
-      const unsigned v = tile32[r * TPD + d];
-      // Rows shared with another workgroup go out write-through and are never left dirty in this
-      // XCD's L2: the bottom 8 rows (handed to row sr+1) and the rows above (their 128-byte lines
-      // are still being completed by row sr-1, two superblocks ahead).
-      if (r >= n || r < 8)
-        st_sc1(gp, v);
-      else
-        *gp = v;
-    }
-    // slide: the right 8 columns become the left strip of the next superblock
-    if (!last && lane < n) {
-#pragma unroll
-      for (int d = 0; d < 8 / PPD; ++d) tile32[(8 + lane) * TPD + d] = tile32[(8 + lane) * TPD + n / PPD + d];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (lane == 0) __hip_atomic_store(progress_mine, last ? sb_cols : sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (last) break;
-  }
-}
-
-
 // Four-wave form of the row walk: wave 0 filters, wave 1 moves data in, wave 2 hands rows to the
 // row below, wave 3 writes the finished superblock back.  Per superblock c:
 //   phase A   wave 0: vertical pass of c, LDS flag.
@@ -543,8 +340,7 @@ __device__ __forceinline__ void lf_row_body(Pix *tile, unsigned *ctl, const vp9h
 template <typename Pix, int N, int SH>
 __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const vp9hip_lfm *__restrict__ lfms,
                                              int sb_cols, int sr, int pl, const LfThreshDev &th, const FrameDev &f,
-                                             int mi_rows, int *vprog_prev, int *hprog_prev, int *vprog_mine,
-                                             int *hprog_mine, int *err, volatile unsigned *flags,
+                                             int mi_rows, int *err, volatile unsigned *flags,
                                              const int *gate_done, const int *gate_expected, int sb_rows,
                                              lf_granule *hand_base, unsigned gen) {
   constexpr int TP = TileCfg<Pix>::TP;
@@ -597,16 +393,6 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     }
     lf_controls<N>(ctls + (sc & 1) * 256, lfms[sr * sb_cols + sc], pl, mi_row, rows_mi, mi_rows, th);
   };
-  auto wait_for = [&](int *ctr, int need) {
-    int spins = 0;
-    while (!dead && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > LF_SPIN_LIMIT) {
-        if (lane == 0) atomicExch(err, 1);
-        dead = true;
-      }
-    }
-  };
   // Running beside the intra island walk (vp9hip_intra_islands_lf): superblock (sr, c) may be loaded
   // and filtered once every island touching superblocks (sr..sr+1, c-1..c+1) is done — an unfinished
   // island there still reads samples this superblock's passes change (its left / above / above-left /
@@ -622,7 +408,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       while (!dead && __hip_atomic_load(&gate_done[r * sb_cols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(4);
         if (++spins > LF_SPIN_LIMIT) {
-          if (lane == 0) atomicExch(err, 1);
+          if (lane == 0) atomicOr(err, 1);
           dead = true;
         }
       }
@@ -656,7 +442,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         if (__builtin_amdgcn_ballot_w64(!ok) == 0 || dead) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > LF_SPIN_LIMIT) {
-          if (lane == 0) atomicExch(err, 1);
+          if (lane == 0) atomicOr(err, 1);
           dead = true;
         }
       }
@@ -772,7 +558,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       for (int spins = 0; flags[0] < (unsigned)(sc + 1); ++spins) {  // wave 0 of this workgroup: bounded all the same
         __builtin_amdgcn_s_sleep(1);
         if (spins > LF_SPIN_LIMIT) {
-          if (lane == 0) atomicExch(err, 1);
+          if (lane == 0) atomicOr(err, 1);
           break;
         }
       }
@@ -807,91 +593,88 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   if (wave == 3) bulk_writeback(ncols - 1, 0);
 }
 
+// LDS of a filter row workgroup
+template <typename Pix>
+struct LfRowLds {
+  __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
+  unsigned ctls[2 * 256];
+  unsigned flags[2];
+};
+
+template <typename Pix, int SH>
+__device__ __forceinline__ void lf_row_entry(LfRowLds<Pix> &L, const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
+                                             const LfThreshDev &th, const FrameDev &f, int mi_rows, int *err,
+                                             const int *gate_done, const int *gate_expected, lf_granule *hand, unsigned gen,
+                                             int sr, int pl) {
+  if (pl == 0 || f.awidth[pl] == f.awidth[0])
+    lf_row2_body<Pix, 64, SH>(L.tiles, L.ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, err, L.flags, gate_done, gate_expected,
+                              sb_rows, hand, gen);
+  else
+    lf_row2_body<Pix, 32, SH>(L.tiles, L.ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, err, L.flags, gate_done, gate_expected,
+                              sb_rows, hand, gen);
+}
+
+// The filter alone: workgroup (r, plane).  Row r waits for row r-1 = a workgroup with a lower index in the grid.
 template <typename Pix, int SH>
 __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
-                                                       LfThreshDev th, FrameDev f, int mi_rows, int *progress,
-                                                       int *err, const int *gate_done, const int *gate_expected,
+                                                       int planes, LfThreshDev th, FrameDev f, int mi_rows, int *err,
                                                        lf_granule *hand, unsigned gen) {
-  __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
-  __shared__ unsigned ctls[2 * 256];
-  __shared__ unsigned flags[2];
-  const int sr = blockIdx.x, pl = blockIdx.y;
-  // progress[0 .. 3*sb_rows): horizontal-pass counters; [3*sb_rows .. 6*sb_rows): vertical-pass counters
-  int *hprev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
-  int *hmine = progress + pl * sb_rows + sr;
-  int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
-  if (pl == 0 || f.awidth[pl] == f.awidth[0])
-    lf_row2_body<Pix, 64, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
-                          gate_done, gate_expected, sb_rows, hand, gen);
-  else
-    lf_row2_body<Pix, 32, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
-                          gate_done, gate_expected, sb_rows, hand, gen);
+  __shared__ LfRowLds<Pix> L;
+  const int sr = (int)blockIdx.x / planes, pl = (int)blockIdx.x % planes;
+  lf_row_entry<Pix, SH>(L, lfms, sb_cols, sb_rows, th, f, mi_rows, err, nullptr, nullptr, hand, gen, sr, pl);
 }
 
-// The island walk and the loop filter of a frame as ONE launch: the filter's rows and one workgroup per island.
-// islands_first_flag == 0: workgroups [0, sb_rows * planes) are the rows (dispatched first, so they are resident
-// before the islands flood the GPU: a filter row waits, bounded, for islands, and islands never wait for
-// anything); != 0: the islands come first in the grid (see the launch site).  No
-// second stream, no fork / join events between the transforms, this pair and the next frame's convolve —
-// every such dependency packet cost the command processor several microseconds between two kernels
-// (rocprofv3 trace of bench.py, DESIGN.md §3.4: 12 us before and 37 us after the pair as two launches).
-template <typename Pix, int SH>
-__global__ __launch_bounds__(256) void walk_lf_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows, int planes,
-                                                      LfThreshDev th, FrameDev f, int mi_rows, int *progress, int *err,
-                                                      int *gate_done, const int *gate_expected,
-                                                      const vp9hip_intra_task *__restrict__ tasks,
-                                                      const vp9hip_intra_island *__restrict__ islands,
-                                                      const int32_t *__restrict__ wave_off, ResidDev rd,
-                                                      const int32_t *__restrict__ coeffs, lf_granule *hand, unsigned gen,
-                                                      int islands_first_flag) {
-  const int n_lf = sb_rows * planes;
-  const int n_isl = (int)gridDim.x - n_lf;
-  const bool islands_first = islands_first_flag != 0;
-  const int lf_index = islands_first ? (int)blockIdx.x - n_isl : (int)blockIdx.x;
-  if (islands_first ? (int)blockIdx.x < n_isl : (int)blockIdx.x >= n_lf) {
-    const int island = islands_first ? (int)blockIdx.x : (int)blockIdx.x - n_lf;
-    if (coeffs != nullptr) {
-      // the residual of the island's coded tasks first (no waves: every task at once, eight at a time), into
-      // the residual scratch the walk then adds from — what intra_residual_kernel does as a launch of its own
-      __shared__ int rtiles[SLOTS][32 * TPITCH];
-      const vp9hip_intra_island isl = islands[island];
-      const int n = wave_off[isl.wave_off_start + isl.n_waves];
-      const int slot = threadIdx.x / SLOT;
-      for (int base = 0; base < n; base += SLOTS)
-        residual_chunk<sizeof(Pix) == 2>(rtiles, tasks, isl.task_start + base + slot, base + slot < n, coeffs, rd, f);
-      __syncthreads();
-    }
-    intra_island_body<Pix, sizeof(Pix) == 2, true>(tasks, islands, wave_off, nullptr, rd, f, gate_done, sb_cols, island);
-    return;
-  }
-  __shared__ __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
-  __shared__ unsigned ctls[2 * 256];
-  __shared__ unsigned flags[2];
-  const int sr = lf_index % sb_rows, pl = lf_index / sb_rows;
-  int *hprev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
-  int *hmine = progress + pl * sb_rows + sr;
-  int *vprev = hprev + 3 * sb_rows, *vmine = hmine + 3 * sb_rows;
-  if (pl == 0 || f.awidth[pl] == f.awidth[0])
-    lf_row2_body<Pix, 64, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
-                              gate_done, gate_expected, sb_rows, hand, gen);
-  else
-    lf_row2_body<Pix, 32, SH>(tiles, ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, vprev, hprev, vmine, hmine, err, flags,
-                              gate_done, gate_expected, sb_rows, hand, gen);
-}
+// Where the filter's rows sit among the islands in the fused launch's grid: the `planes` workgroups of row r
+// start at index pos[r] + r * planes, i.e. behind pos[r] islands.
+constexpr int LF_MAX_ROWS = 128;
+struct RowPos {
+  int pos[LF_MAX_ROWS];
+};
 
 template <typename Pix>
-__global__ __launch_bounds__(64) void lf_rows_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
-                                                     LfThreshDev th, FrameDev f, int mi_rows, int *progress,
-                                                     int *err) {
-  __shared__ __attribute__((aligned(16))) Pix tile[72 * TileCfg<Pix>::TP];
-  __shared__ unsigned ctl[256];
-  const int sr = blockIdx.x, pl = blockIdx.y;
-  int *prev = progress + pl * sb_rows + (sr > 0 ? sr - 1 : 0);
-  int *mine = progress + pl * sb_rows + sr;
-  if (pl == 0 || f.awidth[pl] == f.awidth[0])
-    lf_row_body<Pix, 64>(tile, ctl, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
-  else
-    lf_row_body<Pix, 32>(tile, ctl, lfms, sb_cols, sr, pl, th, f, mi_rows, prev, mine, err);
+union WalkLfLds {
+  IslandLds isl;
+  LfRowLds<Pix> row;
+};
+
+// The island walk and the loop filter of a frame as ONE launch: a workgroup per island (walked in LDS) and a
+// workgroup per (superblock row, plane) of the filter, the latter placed in the grid right behind the last island
+// they can ever wait for (RowPos).  Forward progress by construction: islands wait for nothing; a row waits for the
+// row above (placed before it) and for island marks of superblock rows r, r + 1 (all in front of it); the hardware
+// starts a grid's workgroups in index order, so whoever is waited for is running or done — whatever else shares
+// the GPU.  No second stream, no fork / join events, no residual pre-pass: every dependency packet between two
+// kernels cost the command processor several microseconds (rocprofv3 trace of bench.py).
+// While the frame runs, the first row's workgroup also zero-fills the island counters of the NEXT launch.
+template <typename Pix, int SH>
+#ifndef WALK_LF_WAVES
+#define WALK_LF_WAVES 2
+#endif
+__global__ __launch_bounds__(256, WALK_LF_WAVES) void walk_lf_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows, int planes,
+                                                      LfThreshDev th, FrameDev f, int mi_rows, int *err, int *gate_done,
+                                                      int *gate_next, int n_gate, const int *gate_expected,
+                                                      const vp9hip_intra_task *__restrict__ tasks,
+                                                      const vp9hip_intra_island *__restrict__ islands,
+                                                      const int32_t *__restrict__ wave_off, const int32_t *__restrict__ coeffs,
+                                                      lf_granule *hand, unsigned gen, RowPos rp) {
+  __shared__ WalkLfLds<Pix> S;
+  const int b = (int)blockIdx.x;
+  int k = 0;  // row groups that start at or before b
+  for (int r = 0; r < sb_rows; ++r)
+    if (rp.pos[r] + r * planes <= b) k = r + 1;
+  const int start = k > 0 ? rp.pos[k - 1] + (k - 1) * planes : 0;
+  if (k > 0 && b < start + planes) {
+    const int sr = k - 1, pl = b - start;
+    if (sr == 0 && pl == 0)
+      for (int i = (int)threadIdx.x; i < n_gate; i += 256) gate_next[i] = 0;
+    lf_row_entry<Pix, SH>(S.row, lfms, sb_cols, sb_rows, th, f, mi_rows, err, gate_done, gate_expected, hand, gen, sr, pl);
+    return;
+  }
+  const vp9hip_intra_island isl = islands[b - k * planes];
+  if (!island_lds_body<Pix, sizeof(Pix) == 2>(S.isl, tasks, isl, wave_off, coeffs, f, gate_done, sb_cols)) {
+    // not an island of this launch's kind (vp9hip.h: VP9HIP_ISLAND_FITS): its marks never come, the rows around it
+    // give up after their bounded wait; say why
+    if (threadIdx.x == 0) atomicOr(err, 2);
+  }
 }
 
 }  // namespace
@@ -919,247 +702,115 @@ static int lf_handoff_buffer(vp9hip_ctx *ctx, const vp9hip_frame *frame, int sb_
   return VP9HIP_OK;
 }
 
-static int lf_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
-                     const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes, const int *d_gate,
-                     const int32_t *d_sb_expected, bool counters_zeroed = false) {
+// Argument checks + error flag + hand-off buffer shared by the two launches.
+static int lf_prepare(vp9hip_ctx *ctx, const char *who, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
+                      const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes, unsigned *gen) {
   if (!d_lfm || sb_rows <= 0 || sb_cols <= 0 || !h_thresh || !frame_ok(frame) || (planes != 1 && planes != 3))
-    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_loop_filter_frame: bad argument");
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "%s: bad argument", who);
   if (sb_rows != (frame->aheight[0] + 63) / 64 || sb_cols != (frame->awidth[0] + 63) / 64)
-    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_loop_filter_frame: %dx%d superblocks do not cover a %dx%d frame",
-                sb_cols, sb_rows, frame->awidth[0], frame->aheight[0]);
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "%s: %dx%d superblocks do not cover a %dx%d frame", who, sb_cols, sb_rows,
+                frame->awidth[0], frame->aheight[0]);
   const bool c420 = frame->awidth[1] * 2 == frame->awidth[0] && frame->aheight[1] * 2 == frame->aheight[0];
   const bool c444 = frame->awidth[1] == frame->awidth[0] && frame->aheight[1] == frame->aheight[0];
   if (planes == 3 && !c420 && !c444)
-    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_loop_filter_frame: chroma must be 4:2:0 or 4:4:4 (libvpx's LF_PATH_SLOW is not implemented)");
-  LfThreshDev th;
-  memcpy(&th, h_thresh, sizeof(th));
-  const FrameDev f = to_dev(frame);
-  const int mi_rows = frame->aheight[0] / 8;
-  static int mode = -1;  // 0: one launch per anti-diagonal, 1: row walk (1 wave), 2: row walk (4 waves, the default)
-  if (mode < 0) {
-    const char *e = getenv("VP9HIP_LF_MODE");
-    mode = (e && !strcmp(e, "diag")) ? 0 : (e && !strcmp(e, "rows")) ? 1 : 2;
+    VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "%s: chroma must be 4:2:0 or 4:4:4 (libvpx's LF_PATH_SLOW is not implemented)", who);
+  // the error flag lives in an allocation of its own: it stays set until vp9hip_sync has reported it, however
+  // many frames are enqueued behind the one that gave up
+  if (!ctx->lf_err_flag) {
+    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_err_flag, sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(int)));
   }
-  if (d_gate && mode != 2) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "the overlapped loop filter needs the default row-walk mode");
-  if (mode != 0) {
-    // one launch: a workgroup per (superblock row, plane), progress counters in context scratch
-    const size_t need = (size_t)(6 * sb_rows + 1) * sizeof(int);
-    int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
-    if (rc) return rc;
-    int *progress = (int *)ctx->scratch;
-    if (!counters_zeroed) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, st));
-    // the time-out flag lives OUTSIDE the counters that are zero-filled for every frame: it stays set until
-    // vp9hip_sync has reported it, however many frames are enqueued behind the one that gave up
-    if (!ctx->lf_err_flag) {
-      VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_err_flag, sizeof(int)));
-      VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(int)));
-    }
-    int *err = ctx->lf_err_flag;
-    ctx->lf_err_armed = true;
-    unsigned gen = 0;
-    {
-      int rc2 = lf_handoff_buffer(ctx, frame, sb_rows, &gen);
-      if (rc2) return rc2;
-    }
-    if (mode == 2) {
-// Unused dynamic LDS on top of the kernel's own, so that at most ONE of these workgroups fits a CU (160 KB):
-// a row that waits for islands (vp9hip_intra_islands_lf) must leave the CU's registers to an island
-// workgroup beside it, however many streams are in flight — two filter workgroups on a CU would not.
-// Only the gated launch needs it.  Forward progress of the rows themselves: a row waits for the row above,
-// i.e. for a workgroup with a LOWER blockIdx.x in the same plane; workgroups are dispatched in blockIdx order
-// (x fastest), so the one waited for is always resident or finished — also when sb_rows x planes exceeds the
-// number of CUs (tests/test_gpu_lf.py runs a frame with more rows than that).
-#define LF_LDS_PAD(PIX) (84 * 1024 - (int)sizeof(PIX) * 2 * 72 * 76 - 4096)
-#define LF_ROWS2(PIX, SH)                                                                                       \
-  hipLaunchKernelGGL((lf_rows2_kernel<PIX, SH>), dim3(sb_rows, planes), dim3(256), d_gate ? LF_LDS_PAD(PIX) : 0, st, d_lfm, sb_cols, sb_rows, \
-                     th, f, mi_rows, progress, err, d_gate, d_sb_expected, (lf_granule *)ctx->lf_hand, gen)
-      if (!frame->hbd)
-        LF_ROWS2(uint8_t, 0);
-      else if (frame->bit_depth == 10)
-        LF_ROWS2(uint16_t, 2);
-      else if (frame->bit_depth == 12)
-        LF_ROWS2(uint16_t, 4);
-      else
-        LF_ROWS2(uint16_t, 0);
-#undef LF_ROWS2
-    } else if (frame->hbd)
-      hipLaunchKernelGGL(lf_rows_kernel<uint16_t>, dim3(sb_rows, planes), dim3(64), 0, st, d_lfm, sb_cols,
-                         sb_rows, th, f, mi_rows, progress, err);
-    else
-      hipLaunchKernelGGL(lf_rows_kernel<uint8_t>, dim3(sb_rows, planes), dim3(64), 0, st, d_lfm, sb_cols,
-                         sb_rows, th, f, mi_rows, progress, err);
-    VP9HIP_CHECK(ctx, hipGetLastError());
-    return VP9HIP_OK;
-  }
-  const int t_max = (sb_cols - 1) + 2 * (sb_rows - 1);
-  for (int t = 0; t <= t_max; ++t) {
-    // superblock rows r with 0 <= t - 2r < sb_cols
-    int r_min = (t - (sb_cols - 1) + 1) / 2;
-    if (t - (sb_cols - 1) <= 0) r_min = 0;
-    int r_max = t / 2;
-    if (r_max > sb_rows - 1) r_max = sb_rows - 1;
-    const int cnt = r_max - r_min + 1;
-    if (cnt <= 0) continue;
-    if (frame->hbd)
-      hipLaunchKernelGGL(lf_diag_kernel<uint16_t>, dim3(cnt, planes), dim3(64), 0, st, d_lfm, sb_cols, t,
-                         r_min, th, f, mi_rows);
-    else
-      hipLaunchKernelGGL(lf_diag_kernel<uint8_t>, dim3(cnt, planes), dim3(64), 0, st, d_lfm, sb_cols, t,
-                         r_min, th, f, mi_rows);
-  }
-  VP9HIP_CHECK(ctx, hipGetLastError());
-  return VP9HIP_OK;
+  ctx->lf_err_armed = true;
+  return lf_handoff_buffer(ctx, frame, sb_rows, gen);
 }
 
 extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
                                         const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes) {
   if (!ctx) return VP9HIP_EINVAL;
   VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the caller's thread may be on another device
-  return lf_launch(ctx, ctx->stream, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, nullptr, nullptr);
-}
-
-// Layout of the context scratch the overlapped call uses: the filter's progress counters, then (64-int
-// aligned) one island counter per superblock.
-static inline size_t lf_gate_off(int sb_rows) { return ((size_t)(6 * sb_rows + 1) + 63) & ~(size_t)63; }
-static inline size_t lf_counter_bytes(int sb_rows, int sb_cols) {
-  return (lf_gate_off(sb_rows) + (size_t)sb_rows * sb_cols) * sizeof(int);
-}
-
-// Zero-fill of those counters ahead of time (vp9hip_intra_residual_begin, on its stream): one launch less
-// between the transforms and the walk / the filter.
-int vp9hip_lf_zero_counters(vp9hip_ctx *ctx, const vp9hip_frame *frame, hipStream_t st) {
-  const int sb_rows = (frame->aheight[0] + 63) / 64, sb_cols = (frame->awidth[0] + 63) / 64;
-  const size_t need = lf_counter_bytes(sb_rows, sb_cols);
-  int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
+  unsigned gen = 0;
+  int rc = lf_prepare(ctx, "vp9hip_loop_filter_frame", d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, &gen);
   if (rc) return rc;
-  VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, st));
-  ctx->lf_zeroed_rows = sb_rows;
-  ctx->lf_zeroed_cols = sb_cols;
+  LfThreshDev th;
+  memcpy(&th, h_thresh, sizeof(th));
+  const FrameDev f = to_dev(frame);
+#define LF_ROWS2(PIX, SH)                                                                                               \
+  hipLaunchKernelGGL((lf_rows2_kernel<PIX, SH>), dim3(sb_rows * planes), dim3(256), 0, ctx->stream, d_lfm, sb_cols, sb_rows, \
+                     planes, th, f, frame->aheight[0] / 8, ctx->lf_err_flag, (lf_granule *)ctx->lf_hand, gen)
+  if (!frame->hbd)
+    LF_ROWS2(uint8_t, 0);
+  else if (frame->bit_depth == 10)
+    LF_ROWS2(uint16_t, 2);
+  else if (frame->bit_depth == 12)
+    LF_ROWS2(uint16_t, 4);
+  else
+    LF_ROWS2(uint16_t, 0);
+#undef LF_ROWS2
+  VP9HIP_CHECK(ctx, hipGetLastError());
   return VP9HIP_OK;
 }
 
-constexpr int VP9HIP_GATE_INTS = 16384;  // island counters: up to 128 x 128 superblocks (8192 x 8192 samples)
+// Island counters of the fused launch: two sets in the context scratch, used in turn — a launch counts in one
+// and zero-fills the other for the launch after it (no fill packet in the queue between two frames).
+static int lf_gate_sets(vp9hip_ctx *ctx, int n_gate, int **cur, int **nxt) {
+  const size_t set_ints = ((size_t)n_gate + 63) & ~(size_t)63;
+  if (ctx->gate_n != n_gate) {  // another frame geometry: a launch only zero-fills the n_gate counters of its own
+    int rc = vp9hip_ensure_scratch(ctx, 2 * set_ints * sizeof(int));  // (synchronises when it grows)
+    if (rc) return rc;
+    VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, 2 * set_ints * sizeof(int), ctx->stream));
+    ctx->gate_n = n_gate;
+    ctx->gate_parity = 0;
+  }
+  *cur = (int *)ctx->scratch + (size_t)ctx->gate_parity * set_ints;
+  *nxt = (int *)ctx->scratch + (size_t)(ctx->gate_parity ^ 1) * set_ints;
+  ctx->gate_parity ^= 1;
+  return VP9HIP_OK;
+}
 
-// Intra island walk and loop filter side by side: islands on the context's stream, the loop filter
-// on a second stream; the filter takes a superblock when the islands around it are done (gate
-// counters), not when the whole walk is.  Both kernels are ordered after everything enqueued before
-// (event fork) and the context's stream continues after both (event join).
 extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
                                        const vp9hip_intra_island *d_islands, int n_islands,
                                        const int32_t *d_wave_off, const int32_t *d_coeffs,
-                                       const int32_t *d_sb_expected, const vp9hip_lfm *d_lfm, int sb_rows,
-                                       int sb_cols, const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame,
-                                       int planes) {
+                                       const int32_t *d_sb_expected, const int32_t *h_row_pos, const vp9hip_lfm *d_lfm,
+                                       int sb_rows, int sb_cols, const vp9hip_lf_thresh *h_thresh,
+                                       const vp9hip_frame *frame, int planes) {
   if (!ctx) return VP9HIP_EINVAL;
   VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !d_sb_expected || !frame_ok(frame))
+  if (n_islands == 0) return vp9hip_loop_filter_frame(ctx, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes);
+  if (!d_tasks || !d_islands || n_islands < 0 || !d_wave_off || !d_sb_expected)
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: bad argument");
-  if (sb_rows > 255 || sb_cols > 255 || sb_rows * sb_cols > VP9HIP_GATE_INTS)
+  if (sb_rows > LF_MAX_ROWS || sb_cols > LF_MAX_ROWS)
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: frame too large (%d x %d superblocks)", sb_cols, sb_rows);
-  if (n_islands == 0) return lf_launch(ctx, ctx->stream, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, nullptr, nullptr);
-  if (!ctx->stream2) VP9HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-  if (!ctx->ev_fork) {
-    VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    VP9HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  unsigned gen = 0;
+  int rc = lf_prepare(ctx, "vp9hip_intra_islands_lf", d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, &gen);
+  if (rc) return rc;
+  RowPos rp;
+  memset(&rp, 0, sizeof(rp));
+  for (int r = 0; r < sb_rows; ++r) {
+    rp.pos[r] = h_row_pos ? h_row_pos[r] : n_islands;
+    if (rp.pos[r] < 0 || rp.pos[r] > n_islands || (r > 0 && rp.pos[r] < rp.pos[r - 1]))
+      VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: h_row_pos[%d] = %d is not a non-decreasing island count", r, rp.pos[r]);
   }
-  // one zero-fill for the filter's progress counters and the island counters behind them (scratch must
-  // exist before the fork: growing it synchronises)
-  const size_t gate_off = lf_gate_off(sb_rows);
-  const size_t need = lf_counter_bytes(sb_rows, sb_cols);
-  {
-    int rc = vp9hip_ensure_scratch(ctx, need < 4096 ? 4096 : need);
-    if (rc) return rc;
-  }
-  if (d_coeffs) {
-    int rc = vp9hip_ensure_resid(ctx, frame);
-    if (rc) return rc;
-  }
-  int *d_gate = (int *)ctx->scratch + gate_off;
-  static int two_streams = -1;  // VP9HIP_LF_TWO_STREAMS=1: the earlier form (walk and filter as two launches on two streams)
-  if (two_streams < 0) two_streams = getenv("VP9HIP_LF_TWO_STREAMS") != nullptr;
-  if (!two_streams && d_coeffs) {
-    // ---- one launch for both (walk_lf_kernel) ------------------------------------------------------
-    const bool zeroed1 = ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs && ctx->lf_zeroed_rows == sb_rows &&
-                         ctx->lf_zeroed_cols == sb_cols;
-    ctx->lf_zeroed_rows = ctx->lf_zeroed_cols = 0;
-    if (!zeroed1) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
-    // VP9HIP_FUSED_RESIDUAL=1: the island workgroups also run their tasks' inverse transforms (no pre-pass launch,
-    // no second stream at all).  Measured on the bench frame: one stream 2012 against 2060 frames/s with the
-    // pre-pass beside the convolve, eight streams in flight 3640 against 3075 — the default serves one stream.
-    static int own_resid = -1;
-    if (own_resid < 0) own_resid = getenv("VP9HIP_FUSED_RESIDUAL") != nullptr;
-    const bool prepass_done = ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs;
-    const int32_t *k_coeffs = (own_resid && !prepass_done) ? d_coeffs : nullptr;
-    if (!k_coeffs) {
-      int rc1 = vp9hip_islands_prepare(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame);
-      if (rc1) return rc1;
-    }
-    ctx->resid_tasks = nullptr;
-    if (!d_lfm || !h_thresh || (planes != 1 && planes != 3)) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: bad argument");
-    if (sb_rows != (frame->aheight[0] + 63) / 64 || sb_cols != (frame->awidth[0] + 63) / 64)
-      VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: %dx%d superblocks do not cover a %dx%d frame", sb_cols, sb_rows,
-                  frame->awidth[0], frame->aheight[0]);
-    {
-      const bool c420 = frame->awidth[1] * 2 == frame->awidth[0] && frame->aheight[1] * 2 == frame->aheight[0];
-      const bool c444 = frame->awidth[1] == frame->awidth[0] && frame->aheight[1] == frame->aheight[0];
-      if (planes == 3 && !c420 && !c444) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_islands_lf: chroma must be 4:2:0 or 4:4:4");
-    }
-    if (!ctx->lf_err_flag) {
-      VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_err_flag, sizeof(int)));
-      VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(int)));
-    }
-    ctx->lf_err_armed = true;
-    LfThreshDev th;
-    memcpy(&th, h_thresh, sizeof(th));
-    const FrameDev f = to_dev(frame);
-    const ResidDev rd = resid_dev(ctx, frame);
-    const int grid = sb_rows * planes + n_islands;
-    // Grid order.  One context in the process: the filter's rows first — they are resident before the islands flood
-    // the GPU and the chain starts at once (4 % of the frame).  Several contexts: launches of different contexts run
-    // side by side, and rows that are resident and waiting for their islands can take the slots those islands need
-    // (in-order dispatch per hardware queue: a launch's islands come after ITS rows, but not after the rows of the
-    // other launches) until a row's bounded wait runs out — then the islands go first: a row only ever waits for
-    // workgroups dispatched before it, whatever else is in flight.  VP9HIP_ISLANDS_FIRST=0/1 overrides.
-    static const char *order_env = getenv("VP9HIP_ISLANDS_FIRST");
-    const int islands_first = order_env ? atoi(order_env) != 0 : vp9hip_live_contexts() > 1;
+  int *gate_cur = nullptr, *gate_next = nullptr;
+  const int n_gate = sb_rows * sb_cols;
+  rc = lf_gate_sets(ctx, n_gate, &gate_cur, &gate_next);
+  if (rc) return rc;
+  LfThreshDev th;
+  memcpy(&th, h_thresh, sizeof(th));
+  const FrameDev f = to_dev(frame);
+  const int grid = sb_rows * planes + n_islands;
 #define WALK_LF(PIX, SH)                                                                                              \
   hipLaunchKernelGGL((walk_lf_kernel<PIX, SH>), dim3(grid), dim3(256), 0, ctx->stream, d_lfm, sb_cols, sb_rows, planes, th, f, \
-                     frame->aheight[0] / 8, (int *)ctx->scratch, ctx->lf_err_flag, d_gate, d_sb_expected, d_tasks, d_islands, \
-                     d_wave_off, rd, k_coeffs, (lf_granule *)ctx->lf_hand, gen, islands_first)
-    unsigned gen = 0;
-    {
-      int rc2 = lf_handoff_buffer(ctx, frame, sb_rows, &gen);
-      if (rc2) return rc2;
-    }
-    if (!frame->hbd)
-      WALK_LF(uint8_t, 0);
-    else if (frame->bit_depth == 10)
-      WALK_LF(uint16_t, 2);
-    else if (frame->bit_depth == 12)
-      WALK_LF(uint16_t, 4);
-    else
-      WALK_LF(uint16_t, 0);
+                     frame->aheight[0] / 8, ctx->lf_err_flag, gate_cur, gate_next, n_gate, d_sb_expected, d_tasks, d_islands, \
+                     d_wave_off, d_coeffs, (lf_granule *)ctx->lf_hand, gen, rp)
+  if (!frame->hbd)
+    WALK_LF(uint8_t, 0);
+  else if (frame->bit_depth == 10)
+    WALK_LF(uint16_t, 2);
+  else if (frame->bit_depth == 12)
+    WALK_LF(uint16_t, 4);
+  else
+    WALK_LF(uint16_t, 0);
 #undef WALK_LF
-    VP9HIP_CHECK(ctx, hipGetLastError());
-    return VP9HIP_OK;
-  }
-  // the counters were zero-filled by vp9hip_intra_residual_begin of this frame (on stream2, which the filter
-  // follows in order and the walk waits for), or are now
-  const bool zeroed = d_coeffs && ctx->resid_tasks == d_tasks && ctx->resid_coeffs == d_coeffs &&
-                      ctx->lf_zeroed_rows == sb_rows && ctx->lf_zeroed_cols == sb_cols;
-  ctx->lf_zeroed_rows = ctx->lf_zeroed_cols = 0;
-  if (!zeroed) VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
-  VP9HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-  VP9HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  int rc;
-  // VP9HIP_LF_NOGATE (measurement only, WRONG pixels): the filter does not wait for the islands
-  const bool nogate = getenv("VP9HIP_LF_NOGATE") != nullptr;
-  rc = vp9hip_islands_launch(ctx, ctx->stream, d_tasks, d_islands, n_islands, d_wave_off, d_coeffs, frame, d_gate, sb_cols);
-  if (rc) return rc;
-  rc = lf_launch(ctx, ctx->stream2, d_lfm, sb_rows, sb_cols, h_thresh, frame, planes, nogate ? nullptr : d_gate,
-                 nogate ? nullptr : d_sb_expected, true);
-  // join even if the filter launch failed, so that the context's stream stays ordered
-  (void)hipEventRecord(ctx->ev_join, ctx->stream2);
-  (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
-  return rc;
+  VP9HIP_CHECK(ctx, hipGetLastError());
+  return VP9HIP_OK;
 }

@@ -7,11 +7,6 @@ static char g_err[512] = "no context";
 
 extern "C" int vp9hip_abi_version(void) { return VP9HIP_ABI_VERSION; }
 
-// contexts alive in this process: with more than one, launches of different contexts run side by side and the fused
-// walk + filter launch orders its workgroups for safety rather than for the shortest chain (lf_kernels.hip)
-static int g_live_contexts = 0;
-int vp9hip_live_contexts(void) { return __atomic_load_n(&g_live_contexts, __ATOMIC_RELAXED); }
-
 extern "C" int vp9hip_create(int device, vp9hip_ctx **out) {
   if (!out) return VP9HIP_EINVAL;
   *out = NULL;
@@ -37,33 +32,18 @@ extern "C" int vp9hip_create(int device, vp9hip_ctx **out) {
   hipDeviceProp_t prop;
   ctx->cu_count = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
   ctx->err[0] = 0;
-  __atomic_add_fetch(&g_live_contexts, 1, __ATOMIC_RELAXED);
   *out = ctx;
   return VP9HIP_OK;
 }
 
 extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   if (!ctx) return;
-  __atomic_sub_fetch(&g_live_contexts, 1, __ATOMIC_RELAXED);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->lf_err_flag) (void)hipFree(ctx->lf_err_flag);
   if (ctx->lf_hand) (void)hipFree(ctx->lf_hand);
-  if (ctx->resid) (void)hipFree(ctx->resid);
-  if (ctx->ev_resid_start) {
-    (void)hipEventDestroy(ctx->ev_resid_start);
-    (void)hipEventDestroy(ctx->ev_resid_done);
-  }
   if (ctx->d_taps) (void)hipFree(ctx->d_taps);
-  if (ctx->stream2) {
-    if (ctx->ev_fork) {
-      (void)hipEventDestroy(ctx->ev_fork);
-      (void)hipEventDestroy(ctx->ev_join);
-    }
-    (void)hipStreamDestroy(ctx->stream2);
-  }
   if (ctx->ev_begin) {
     for (int i = 0; i < VP9HIP_TIMER_SLOTS; ++i) {
       if (ctx->ev_begin[i]) (void)hipEventDestroy(ctx->ev_begin[i]);
@@ -89,6 +69,10 @@ extern "C" int vp9hip_sync(vp9hip_ctx *ctx) {
     ctx->lf_err_armed = false;
     if (flag) {
       VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(int)));  // reported once
+      if (flag & 2)
+        VP9HIP_FAIL(ctx, VP9HIP_EINVAL,
+                    "vp9hip_intra_islands_lf: an island does not fit the LDS window (VP9HIP_ISLAND_FITS) — such islands go to "
+                    "vp9hip_intra_pred_islands first; the frames enqueued since the last synchronisation are not valid");
       VP9HIP_FAIL(ctx, VP9HIP_EDEVICE,
                   "loop filter: a superblock row gave up waiting (for the row above or for the intra islands around it); "
                   "the frames enqueued since the last synchronisation are not valid");

@@ -511,24 +511,11 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
     DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_run: destination slot geometry differs from the frame parameters");
   DEC_HIP(dec, hipSetDevice(dec->ctx->device));
   hipStream_t st = dec->ctx->stream;
-  // a run that failed half-way may have left the head-start bookkeeping of its frame behind (the residual
-  // pre-pass and the zero-filled counters are matched to the island launch by pointer): start clean
-  dec->ctx->resid_tasks = nullptr;
-  dec->ctx->resid_coeffs = nullptr;
-  dec->ctx->lf_zeroed_rows = dec->ctx->lf_zeroed_cols = 0;
   // lists + coefficients: usually long in HBM when a replayed or pipelined frame is run — then no
   // dependency packet goes into the queue (every marker / barrier packet costs the command processor
   // microseconds between two kernels)
   if (hipEventQuery(S->uploaded) != hipSuccess) DEC_HIP(dec, hipStreamWaitEvent(st, S->uploaded, 0));
   if (!dec->timing_off) DEC_CTX(dec, vp9hip_timer_begin(dec->ctx, TIMER_RUN));
-
-  // coefficient mode: the island tasks' inverse transforms only need the coefficients — they start beside
-  // the convolve and the inter transforms (in residual-plane mode the residual is gathered later)
-  static const bool prepass = getenv("VP9HIP_FUSED_RESIDUAL") == nullptr;  // else the fused kernel does it
-  if (prepass && (phases & VP9HIP_PHASE_INTER) && (phases & VP9HIP_PHASE_INTRA) && P->n_islands && S->have_coeffs && !dec->have_res)
-    DEC_CTX(dec, vp9hip_intra_residual_begin(dec->ctx, (const vp9hip_intra_task *)S->d_isl_tasks.p,
-                                             (const vp9hip_intra_island *)S->d_islands.p, P->n_islands,
-                                             (const int32_t *)S->d_wave_off.p, (const int32_t *)S->d_coeffs.p, dst));
 
   const bool do_pred = (phases & (VP9HIP_PHASE_INTER | VP9HIP_PHASE_INTER_PRED)) != 0;
   const bool do_resid = (phases & (VP9HIP_PHASE_INTER | VP9HIP_PHASE_INTER_RESID)) != 0;
@@ -584,22 +571,25 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
       }
       DEC_HIP(dec, hipGetLastError());
     }
-    // islands and the loop filter side by side when both phases are asked for and nothing forces the
-    // sequence (key frames' large components, an explicit mask array that must be uploaded first is fine)
-    const bool overlap = (phases & VP9HIP_PHASE_LF) && thresh && P->n_islands && !P->n_intra_big_tasks && P->sb_rows <= 128 && P->sb_cols <= 128 &&
-                         P->island_sb_expected &&
-                         (h_lfm || P->lfm);
+    // islands and the loop filter as one launch when both phases are asked for and nothing forces the
+    // sequence (key frames' large components; an explicit mask array that must be uploaded first is fine).
+    // Islands too wide for the LDS walk (the tail of the list) go through memory first.
+    const bool overlap = (phases & VP9HIP_PHASE_LF) && thresh && P->n_islands_lds && !P->n_intra_big_tasks && P->sb_rows <= 128 &&
+                         P->sb_cols <= 128 && P->island_sb_expected && P->island_row_pos && (h_lfm || P->lfm);
     if (overlap) {
       if (h_lfm) {
         int rc = dv_upload(dec, &S->d_lfm, h_lfm, sizeof(vp9hip_lfm) * (size_t)P->sb_rows * P->sb_cols);
         if (rc) return rc;
         DEC_HIP(dec, hipStreamSynchronize(st));
       }
+      if (P->n_islands > P->n_islands_lds)
+        DEC_CTX(dec, vp9hip_intra_pred_islands(dec->ctx, (const vp9hip_intra_task *)S->d_isl_tasks.p,
+                                               (const vp9hip_intra_island *)S->d_islands.p + P->n_islands_lds,
+                                               P->n_islands - P->n_islands_lds, (const int32_t *)S->d_wave_off.p, coeffs, dst));
       DEC_CTX(dec, vp9hip_intra_islands_lf(dec->ctx, (const vp9hip_intra_task *)S->d_isl_tasks.p,
-                                           (const vp9hip_intra_island *)S->d_islands.p, P->n_islands,
+                                           (const vp9hip_intra_island *)S->d_islands.p, P->n_islands_lds,
                                            (const int32_t *)S->d_wave_off.p, coeffs, (const int32_t *)S->d_sb_expected.p,
-                                           (const vp9hip_lfm *)S->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst,
-                                           3));
+                                           P->island_row_pos, (const vp9hip_lfm *)S->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst, 3));
       phases &= ~VP9HIP_PHASE_LF;
     } else {
       if (P->n_islands)

@@ -24,16 +24,8 @@ struct vp9hip_ctx {
   unsigned lf_gen;   // generation number of the last launch
   void *d_taps;  // packed i8 convolve taps (inter fast path)
   hipEvent_t *ev_begin, *ev_end;  // VP9HIP_TIMER_SLOTS each, created lazily
-  // overlap of the intra island walk with the loop filter (vp9hip_intra_islands_lf)
-  hipStream_t stream2;
-  hipEvent_t ev_fork, ev_join;
-  // residual of the intra island tasks, computed ahead of the walk (intra_kernels.hip): int32 per sample
-  void *resid;
-  size_t resid_bytes;
-  // vp9hip_intra_residual_begin: the pre-pass already runs on stream2 for these lists; the walk waits for it
-  hipEvent_t ev_resid_start, ev_resid_done;
-  const void *resid_tasks, *resid_coeffs;
-  int lf_zeroed_rows, lf_zeroed_cols;  // vp9hip_intra_residual_begin also zero-filled the filter / island counters
+  // island counters of the fused walk + filter launch (lf_kernels.hip): two sets in `scratch`, used in turn
+  int gate_n, gate_parity;
 };
 
 #define VP9HIP_FAIL(ctx, code, ...)                          \
@@ -87,14 +79,5 @@ static inline int frame_ok(const vp9hip_frame *f) {
 }
 
 int vp9hip_ensure_scratch(vp9hip_ctx *ctx, size_t bytes);
-int vp9hip_live_contexts(void);  /* contexts alive in this process */
-int vp9hip_ensure_resid(vp9hip_ctx *ctx, const vp9hip_frame *frame);
-int vp9hip_lf_zero_counters(vp9hip_ctx *ctx, const vp9hip_frame *frame, hipStream_t st);
-int vp9hip_islands_prepare(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
-                           const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
-                           const int32_t *d_coeffs, const vp9hip_frame *frame);
-int vp9hip_islands_launch(vp9hip_ctx *ctx, hipStream_t st, const vp9hip_intra_task *d_tasks,
-                          const vp9hip_intra_island *d_islands, int n_islands, const int32_t *d_wave_off,
-                          const int32_t *d_coeffs, const vp9hip_frame *frame, int *d_sb_done, int sb_cols);
 
 #endif

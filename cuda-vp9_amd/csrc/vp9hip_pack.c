@@ -42,7 +42,7 @@ struct vp9hip_packer {
   vec inter, inter_sorted, txb, txb_sorted, intra, intra_isl, intra_big, islands, wave_off, big_wave_start;
   vec level, parent, comp_id, comp_size, order_a, order_b, count;
   vec lvl_map[3], own_map[3];
-  vec lfm, lf_raw, rows_expected, lf_skip;
+  vec lfm, lf_raw, rows_expected, lf_skip, comp_box, row_pos;
 };
 
 /* Contents are kept when a vector grows (some are appended to across passes).  Only the vectors the
@@ -99,7 +99,7 @@ void vp9hip_packer_destroy(vp9hip_packer *pk) {
                  &pk->intra_big, &pk->islands,     &pk->wave_off,  &pk->big_wave_start, &pk->level, &pk->parent,
                  &pk->comp_id,  &pk->comp_size,    &pk->order_a,   &pk->order_b,    &pk->count,    &pk->lvl_map[0],
                  &pk->lvl_map[1], &pk->lvl_map[2], &pk->own_map[0], &pk->own_map[1], &pk->own_map[2], &pk->lfm,
-                 &pk->lf_raw,   &pk->rows_expected, &pk->lf_skip };
+                 &pk->lf_raw,   &pk->rows_expected, &pk->lf_skip,   &pk->comp_box,   &pk->row_pos };
   for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) {
     if (!all[i]->p) continue;
     if (pk->release && vec_is_output(pk, all[i])) pk->release(pk->alloc_user, all[i]->p);
@@ -376,27 +376,63 @@ static void counting_sort(const void *src, void *dst, size_t rec, const int32_t 
     memcpy((char *)dst + (size_t)count[key[i]]++ * rec, (const char *)src + (size_t)i * rec, rec);
 }
 
-/* Order of the islands = order in which the island kernel's workgroups are dispatched (a frame has more
- * islands than the GPU holds workgroups).  The loop filter running beside the walk reaches superblock
- * (r, c) after about (r + c) superblock steps and needs every island around it finished by then, and an
- * island takes its depth in waves: earliest deadline first, deadline = (first row + first column) steps
- * minus the island's own duration (a step of the filter is about 2.2 wave times of the walk; measured,
- * DESIGN.md §3.3).  Deepest-first, the previous order, made the filter's first superblocks wait for the
- * shallow islands next to them, which were dispatched last. */
+/* Order of the islands = order in which their workgroups are dispatched.  The loop filter running beside the
+ * walk (vp9hip_intra_islands_lf) reaches superblock (r, c) after about (r + c) superblock steps and needs every
+ * island around it finished by then, and an island takes its depth in waves: earliest deadline first, deadline =
+ * (first row + first column) steps minus the island's own duration (a step of the filter is about 2.2 wave times
+ * of the walk; measured).  In front of that: the islands that fit the LDS window before the
+ * others (two lists for the frame driver), and among the former the group g = max(first superblock row - 1, 0)
+ * — filter row r is placed behind the islands of groups <= r in the fused launch's grid, which are all the
+ * islands that touch superblock rows <= r + 1, i.e. all it ever waits for.  Sort flags ride in the top bits of
+ * n_waves while the list is sorted. */
+#define ISL_WIDE_BIT 0x80000000u
 static int g_isl_w[3] = { 56, 60, 0 };
+static int island_group(const vp9hip_intra_island *x) {
+  const int r = (int)(x->reserved & 255);
+  return r > 0 ? r - 1 : 0;
+}
 static int island_key(const vp9hip_intra_island *x) {
   int r = (int)(x->reserved & 255), c = (int)((x->reserved >> 16) & 255);
   if (g_isl_w[2]) {
     r = r > 0 ? r - 1 : 0;
     c = c > 0 ? c - 1 : 0;
   }
-  return g_isl_w[0] * (r + c) - g_isl_w[1] * (int)x->n_waves;
+  return g_isl_w[0] * (r + c) - g_isl_w[1] * (int)(x->n_waves & ~ISL_WIDE_BIT);
 }
 static int island_deadline_first(const void *a, const void *b) {
   const vp9hip_intra_island *x = (const vp9hip_intra_island *)a, *y = (const vp9hip_intra_island *)b;
+  const unsigned wx = x->n_waves & ISL_WIDE_BIT, wy = y->n_waves & ISL_WIDE_BIT;
+  if (wx != wy) return wx ? 1 : -1;
+  if (!wx) {
+    const int gx = island_group(x), gy = island_group(y);
+    if (gx != gy) return gx < gy ? -1 : 1;
+  }
   const int kx = island_key(x), ky = island_key(y);
   if (kx != ky) return kx < ky ? -1 : 1;
   return x->task_start < y->task_start ? -1 : (x->task_start > y->task_start);
+}
+
+/* per component (later: per island group): the bounding box of its blocks in every plane + the number of full
+ * 32x32 transforms — what VP9HIP_ISLAND_FITS looks at */
+typedef struct {
+  int32_t box[3][4]; /* x0, y0, x1, y1 in samples of the plane */
+  int32_t n_tx32;
+} comp_box;
+static void comp_box_init(comp_box *b) {
+  for (int p = 0; p < 3; ++p) {
+    b->box[p][0] = b->box[p][1] = INT_MAX;
+    b->box[p][2] = b->box[p][3] = 0;
+  }
+  b->n_tx32 = 0;
+}
+static void comp_box_union(comp_box *d, const comp_box *a, const comp_box *b) {
+  for (int p = 0; p < 3; ++p) {
+    d->box[p][0] = a->box[p][0] < b->box[p][0] ? a->box[p][0] : b->box[p][0];
+    d->box[p][1] = a->box[p][1] < b->box[p][1] ? a->box[p][1] : b->box[p][1];
+    d->box[p][2] = a->box[p][2] > b->box[p][2] ? a->box[p][2] : b->box[p][2];
+    d->box[p][3] = a->box[p][3] > b->box[p][3] ? a->box[p][3] : b->box[p][3];
+  }
+  d->n_tx32 = a->n_tx32 + b->n_tx32;
 }
 
 static int uf_find(int32_t *parent, int a) {
@@ -1111,12 +1147,28 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
    * components; a workgroup each filled the GPU with mostly idle lanes (island walk of the bench frame:
    * 5853 workgroups, 190 us of the whole GPU).  Levels are per block, so blocks of different components
    * simply share waves; the per-superblock completion marks work on islands, whatever they contain. */
+  comp_box *cbox = NULL;
   if (n_comp) {
     const size_t n_sb_all = (size_t)sb_rows * sb_cols;
-    if (vec_reserve(&pk->lvl_map[0], sizeof(int32_t) * (size_t)(n_comp + 1)) || vec_reserve(&pk->lvl_map[1], sizeof(int32_t) * (n_sb_all + 1)))
+    if (vec_reserve(&pk->lvl_map[0], sizeof(int32_t) * (size_t)(n_comp + 1)) || vec_reserve(&pk->lvl_map[1], sizeof(int32_t) * (n_sb_all + 1)) ||
+        vec_reserve(&pk->comp_box, sizeof(comp_box) * (size_t)(n_comp + 1)))
       PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
     int32_t *grp = (int32_t *)pk->lvl_map[0].p, *sb_group = (int32_t *)pk->lvl_map[1].p;
-    for (int c = 0; c < n_comp; ++c) grp[c] = -1;
+    cbox = (comp_box *)pk->comp_box.p;
+    for (int c = 0; c < n_comp; ++c) {
+      grp[c] = -1;
+      comp_box_init(&cbox[c]);
+    }
+    for (int i = 0; i < na; ++i) {
+      const vp9hip_intra_task *t = &ia[i];
+      int32_t *b = cbox[comp[i]].box[t->plane];
+      const int bsz = 4 << t->tx_size;
+      if (t->x < b[0]) b[0] = t->x;
+      if (t->y < b[1]) b[1] = t->y;
+      if (t->x + bsz > b[2]) b[2] = t->x + bsz;
+      if (t->y + bsz > b[3]) b[3] = t->y + bsz;
+      if (t->tx_size == 3 && t->eob > 1) ++cbox[comp[i]].n_tx32;
+    }
     for (size_t s = 0; s < n_sb_all; ++s) sb_group[s] = -1;
     for (int i = 0; i < na; ++i) {
       const int c = comp[i];
@@ -1129,12 +1181,23 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
       if (q > sb_rows - 1) q = sb_rows - 1;
       if (c2 > sb_cols - 1) c2 = sb_cols - 1;
       const int sb = q * sb_cols + c2, g = sb_group[sb];
-      if (g >= 0 && csize[g] + csize[c] <= ISLAND_GROUP_TASKS) {
-        grp[c] = g;
-        csize[g] += csize[c];
-        csize[c] = 0;
-      } else {
+      if (g < 0) {
         sb_group[sb] = c;
+      } else if (csize[g] + csize[c] <= ISLAND_GROUP_TASKS) {
+        /* together only while the group's window still fits the LDS of a workgroup: a component that reaches far
+         * into the neighbours stays on its own instead of widening the window of everything around it */
+        comp_box u;
+        comp_box_union(&u, &cbox[g], &cbox[c]);
+        if (VP9HIP_ISLAND_FITS(u.box, csize[g] + csize[c], u.n_tx32)) {
+          grp[c] = g;
+          csize[g] += csize[c];
+          csize[c] = 0;
+          cbox[g] = u;
+        } else if (!VP9HIP_ISLAND_FITS(cbox[g].box, csize[g], cbox[g].n_tx32)) {
+          sb_group[sb] = c; /* the superblock's first component is too wide itself: gather the rest around this one */
+        }
+      } else {
+        sb_group[sb] = c; /* as before: a full group is closed, the next one starts here */
       }
     }
     for (int i = 0; i < na; ++i) comp[i] = grp[comp[i]];
@@ -1252,6 +1315,9 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
          * bit 0 of `reserved`: when its wave is done the island is done with that superblock, and the
          * island kernel says so to the loop filter (vp9hip_intra_islands_lf); island_sb_expected counts the
          * marks per superblock.  A transform block never straddles superblocks. */
+        /* (counted for the islands of the fused launch only: the others are walked before it) */
+        const int fits = VP9HIP_ISLAND_FITS(cbox[c].box, e - a, cbox[c].n_tx32);
+        if (!fits) r->n_waves |= ISL_WIDE_BIT;
         for (int k = e - 1; k >= a; --k) {
           vp9hip_intra_task *t = &isl[k];
           const int sc = t->plane ? ss : 0;
@@ -1263,7 +1329,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
           if (sb_stamp[sb] != n_is) { /* n_is = 1-based id of this island */
             sb_stamp[sb] = n_is;
             t->reserved = 1;
-            ++rexp[sb];
+            if (fits) ++rexp[sb];
           }
         }
         a = e;
@@ -1273,6 +1339,22 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
         if (e) sscanf(e, "%d,%d,%d", &g_isl_w[0], &g_isl_w[1], &g_isl_w[2]);
       }
       qsort(is, (size_t)n_is, sizeof(*is), island_deadline_first);
+      if (vec_reserve(&pk->row_pos, sizeof(int32_t) * (size_t)(sb_rows + 1))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
+      int32_t *rpos = (int32_t *)pk->row_pos.p;
+      memset(rpos, 0, sizeof(int32_t) * (size_t)(sb_rows + 1));
+      int n_lds = 0;
+      for (int k = 0; k < n_is; ++k) {
+        if (is[k].n_waves & ISL_WIDE_BIT) {
+          is[k].n_waves &= ~ISL_WIDE_BIT;
+          continue;
+        }
+        ++n_lds;
+        const int g = island_group(&is[k]);
+        ++rpos[g < sb_rows ? g : sb_rows - 1];
+      }
+      for (int r = 1; r < sb_rows; ++r) rpos[r] += rpos[r - 1];
+      out->island_row_pos = rpos;
+      out->n_islands_lds = n_lds;
       out->islands = is;
       out->n_islands = n_is;
       out->island_wave_off = wo;

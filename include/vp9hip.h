@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VP9HIP_ABI_VERSION 1
+#define VP9HIP_ABI_VERSION 2
 
 enum {
   VP9HIP_OK = 0,
@@ -179,10 +179,17 @@ int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
 
 /* Island form of the same thing, ONE launch: an island is a connected component of the intra
  * dependency graph (in an inter frame: an isolated intra block or a cluster of them; inter
- * blocks are already reconstructed and cut the graph).  Records of an island are contiguous in
- * d_tasks starting at task_start, sorted by wave; d_wave_off[wave_off_start + w] is the offset
- * (relative to task_start) of its wave w, with one extra end entry.  Islands are independent, one
- * workgroup walks one island.  Use vp9hip_intra_pred_waves for very large islands (key frames). */
+ * blocks are already reconstructed and cut the graph), or several small components walked together.
+ * Records of an island are contiguous in d_tasks starting at task_start, sorted by wave;
+ * d_wave_off[wave_off_start + w] is the offset (relative to task_start) of its wave w, with one extra
+ * end entry.  Islands are independent, one workgroup walks one island.  Use vp9hip_intra_pred_waves
+ * for very large islands (key frames).
+ *
+ * An island whose sample window fits the workgroup's LDS is walked there: the window (per plane the
+ * bounding box of its blocks, one row above, one column to the left, four columns to the right) is read
+ * once, the residual of every coded block goes into the window as int16 (saturated: clip(pred + res) is
+ * the same), the waves then read edges from and write predictions to LDS only, and the island's blocks
+ * are written to the frame once at the end.  VP9HIP_ISLAND_FITS says which islands qualify. */
 typedef struct vp9hip_intra_island {
   uint32_t task_start;
   uint32_t wave_off_start;
@@ -190,22 +197,24 @@ typedef struct vp9hip_intra_island {
   uint32_t reserved; /* the LUMA superblocks the island's samples lie in: first row | last row << 8 | first
                         column << 16 | last column << 24 (needed by vp9hip_intra_islands_lf only) */
 } vp9hip_intra_island; /* 16 bytes */
+/* LDS window of an island: int16 elements in all, tasks cached in LDS, full 32x32 transforms per island */
+#define VP9HIP_ISLAND_TILE_ELEMS 8192
+#define VP9HIP_ISLAND_MAX_TASKS 384
+#define VP9HIP_ISLAND_MAX_TX32 16
+/* row pitch (elements) of a plane window whose blocks span w samples: w + 1 (left) + 4 (above-right of a 4x4
+ * block), rounded up to an odd number of dwords */
+#define VP9HIP_ISLAND_PITCH(w) (((((w) + 6) & ~1) & 2) ? (((w) + 6) & ~1) : ((((w) + 6) & ~1) + 2))
+/* box[p] = { x0, y0, x1, y1 } of the island's blocks in plane p (x1 <= x0: no block in that plane) */
+#define VP9HIP_ISLAND_PLANE_ELEMS(b) ((b)[2] > (b)[0] ? VP9HIP_ISLAND_PITCH((b)[2] - (b)[0]) * ((b)[3] - (b)[1] + 1) : 0)
+#define VP9HIP_ISLAND_FITS(box, n_tasks, n_tx32)                                                                        \
+  ((n_tasks) <= VP9HIP_ISLAND_MAX_TASKS && (n_tx32) <= VP9HIP_ISLAND_MAX_TX32 &&                                        \
+   VP9HIP_ISLAND_PLANE_ELEMS((box)[0]) + VP9HIP_ISLAND_PLANE_ELEMS((box)[1]) + VP9HIP_ISLAND_PLANE_ELEMS((box)[2]) <= \
+       VP9HIP_ISLAND_TILE_ELEMS)
+/* Any islands: those that fit are walked in LDS, the others through the frame in memory. */
 int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
                               const vp9hip_intra_island *d_islands, int n_islands,
                               const int32_t *d_wave_off /* DEVICE */, const int32_t *d_coeffs,
                               const vp9hip_frame *frame);
-/* Optional head start for the island calls (vp9hip_intra_pred_islands / vp9hip_intra_islands_lf): the
- * inverse transforms of the island tasks depend on the coefficients only, so they can run beside the
- * frame's convolve and transform launches.  Call it BEFORE those, with the arguments the island call
- * of the same frame will get; it runs on a second stream inside the context, ordered after everything
- * enqueued so far, into context-owned scratch, and the island call waits for it (the zero-fill of the
- * counters vp9hip_intra_islands_lf uses rides along).  Skipping the call
- * only costs the overlap.  A begin is consumed by the NEXT island call on the context with the same
- * d_tasks / d_coeffs pointers, so do not change the contents of those buffers in between. */
-int vp9hip_intra_residual_begin(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks,
-                                const vp9hip_intra_island *d_islands, int n_islands,
-                                const int32_t *d_wave_off /* DEVICE */, const int32_t *d_coeffs,
-                                const vp9hip_frame *frame);
 
 /* ------------------------------------------------------------------------------------------
  * (a11–a12) loop filter of a whole frame.  Per 64x64 superblock one vp9hip_lfm record (the
@@ -235,24 +244,31 @@ int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_ro
                              const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame,
                              int planes /* 1: Y only, 3: Y,U,V */);
 
-/* The island walk and the loop filter of the same frame side by side — one launch (walk_lf_kernel: the
- * filter's rows are the first workgroups, the islands the rest; VP9HIP_LF_TWO_STREAMS=1 selects the earlier form,
- * two launches on two HIP streams of the context):
- * the filter takes superblock (r, c) once the islands touching superblocks (r..r+1, c-1..c+1) are done
- * (an unfinished island there would still read samples the filter changes), not when the whole walk
- * is.  The hand-over is per (island, superblock): bit 0 of vp9hip_intra_task.reserved marks the LAST
- * task of its island inside a luma superblock (list order = wave order), and d_sb_expected (DEVICE,
- * sb_rows * sb_cols entries) = number of marked tasks per superblock (vp9hip_pack.h fills both;
- * islands[i].reserved = the superblock bounding box of an island is informational).  Frames with
- * very large components (key frames: the vp9hip_intra_pred_waves remainder) use the two calls in
- * sequence instead.  Ordered after everything enqueued before on the context, and later work is
- * ordered after both.  At most 255 superblocks in either direction and 16384 in all (128 x 128: 8192 x 8192
- * samples); larger frames are refused here — the frame driver (vp9hip_decoder_run) then runs the two phases in
- * sequence. */
+/* The island walk and the loop filter of the same frame as ONE launch (walk_lf_kernel): a workgroup per island
+ * and a workgroup per (superblock row, plane) of the filter.  The filter takes superblock (r, c) once the islands
+ * touching superblocks (r..r+1, c-1..c+1) are done (an unfinished island there would still read samples the
+ * filter changes), not when the whole walk is.  The hand-over is per (island, superblock): bit 0 of
+ * vp9hip_intra_task.reserved marks the LAST task of its island inside a luma superblock (list order = wave
+ * order), and d_sb_expected (DEVICE, sb_rows * sb_cols entries) = number of marked tasks per superblock
+ * (vp9hip_pack.h fills both).  Every island must fit the LDS window (VP9HIP_ISLAND_FITS; vp9hip_pack.h lists the
+ * others separately: run them with vp9hip_intra_pred_islands first); one that does not is reported by vp9hip_sync.
+ *
+ * Forward progress by construction: a workgroup only ever waits for workgroups with a LOWER index in the same
+ * grid — islands wait for nothing, a filter row waits for the row above and for islands in front of it — and the
+ * hardware starts the workgroups of a grid in index order, so whatever else shares the GPU (other contexts, other
+ * processes) every wait ends.  h_row_pos (HOST, sb_rows entries, non-decreasing, or NULL) says where the rows sit
+ * in the grid: h_row_pos[r] = number of islands in front of the workgroups of filter row r, which must include
+ * every island that touches superblock rows <= r + 1 (vp9hip_pack.h sorts the islands accordingly); NULL puts all
+ * islands first.  Rows start as early as their islands allow instead of behind the whole walk.
+ *
+ * Frames with very large components (key frames: the vp9hip_intra_pred_waves remainder) use the calls in
+ * sequence instead.  Ordered after everything enqueued before on the context, and later work is ordered after it.
+ * At most 128 superblocks in either direction (8192 x 8192 samples); larger frames are refused here — the frame
+ * driver (vp9hip_decoder_run) then runs the phases in sequence. */
 int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task *d_tasks, const vp9hip_intra_island *d_islands,
                             int n_islands, const int32_t *d_wave_off, const int32_t *d_coeffs,
-                            const int32_t *d_sb_expected, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
-                            const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes);
+                            const int32_t *d_sb_expected, const int32_t *h_row_pos, const vp9hip_lfm *d_lfm, int sb_rows,
+                            int sb_cols, const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes);
 
 #ifdef __cplusplus
 }

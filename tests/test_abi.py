@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(hip):
     assert "vp9hip_idct_add_batch" in names and "vp9hip_loop_filter_frame" in names
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, f"declared in include/*.h but not exported by libvp9hip.so: {missing}"
-    assert lib.vp9hip_abi_version() == 1
+    assert lib.vp9hip_abi_version() == 2
 
 
 def test_shim_exports_the_reference_call_surface():

@@ -254,17 +254,46 @@ def intra_levels(tasks, dims, want_components=False):
     return lv
 
 
-def island_sb_expected(isl_tasks, islands, sb_rows, sb_cols):
+def island_pitch(w):
+    """VP9HIP_ISLAND_PITCH (include/vp9hip.h): row pitch of a plane window whose blocks span w samples."""
+    p = (w + 6) & ~1
+    return p if (p & 2) else p + 2
+
+
+ISLAND_TILE_ELEMS, ISLAND_MAX_TASKS, ISLAND_MAX_TX32 = 8192, 384, 16
+
+
+def island_fits(t):
+    """VP9HIP_ISLAND_FITS for the tasks of one island: does its sample window fit the LDS of a workgroup?"""
+    if len(t) > ISLAND_MAX_TASKS or int(((t["tx_size"] == 3) & (t["eob"] > 1)).sum()) > ISLAND_MAX_TX32:
+        return False
+    elems = 0
+    bs = 4 << t["tx_size"].astype(np.int64)
+    for p in range(3):
+        m = t["plane"] == p
+        if not m.any():
+            continue
+        x0, y0 = int(t["x"][m].min()), int(t["y"][m].min())
+        x1, y1 = int((t["x"][m] + bs[m]).max()), int((t["y"][m] + bs[m]).max())
+        elems += island_pitch(x1 - x0) * (y1 - y0 + 1)
+    return elems <= ISLAND_TILE_ELEMS
+
+
+def island_sb_expected(isl_tasks, islands, sb_rows, sb_cols, wave_off=None, n_lds=None):
     """Marks, per island, the LAST task (list order = wave order) inside each luma superblock with bit 0 of
-    `reserved` — when its wave is done the island is done with that superblock, which the island kernel
-    reports to the loop filter running beside it — and returns expected[r * sb_cols + c] = number of
-    marks in superblock (r, c) (vp9hip_intra_islands_lf; mirrors vp9hip_pack.c)."""
+    `reserved` — when the island is done with that superblock the island kernel reports it to the loop filter
+    running beside it — and returns expected[r * sb_cols + c] = number of marks in superblock (r, c) by the
+    first n_lds islands (those of the fused launch; default: all) (vp9hip_intra_islands_lf; mirrors vp9hip_pack.c)."""
     exp = np.zeros(sb_rows * sb_cols, np.int32)
     isl_tasks["reserved"] = 0
-    wave_ends = None
-    starts = np.sort(islands["task_start"].astype(np.int64)) if len(islands) else np.zeros(0, np.int64)
-    ends = np.r_[starts[1:], len(isl_tasks)]
-    for a, b in zip(starts, ends):
+    if n_lds is None:
+        n_lds = len(islands)
+    if wave_off is None:
+        starts = np.sort(islands["task_start"].astype(np.int64)) if len(islands) else np.zeros(0, np.int64)
+        end_of = dict(zip(starts.tolist(), np.r_[starts[1:], len(isl_tasks)].tolist()))
+    for k, r in enumerate(islands):
+        a = int(r["task_start"])
+        b = a + int(wave_off[r["wave_off_start"] + r["n_waves"]]) if wave_off is not None else end_of[a]
         t = isl_tasks[a:b]
         sc = np.where(t["plane"] > 0, 1, 0)
         sb = np.minimum((t["y"].astype(np.int64) << sc) >> 6, sb_rows - 1) * sb_cols + \
@@ -274,24 +303,28 @@ def island_sb_expected(isl_tasks, islands, sb_rows, sb_cols):
         _, first_in_rev = np.unique(rev, return_index=True)
         last = len(sb) - 1 - first_in_rev
         isl_tasks["reserved"][a + last] = 1
-        np.add.at(exp, sb[last], 1)
+        if k < n_lds:
+            np.add.at(exp, sb[last], 1)
     return exp
 
 
-def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
+def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096, sb_rows=None):
     """Split the intra tasks into islands (one workgroup each, vp9hip_intra_pred_islands) and a
-    remainder of very large components that keeps the per-wave launches."""
+    remainder of very large components that keeps the per-wave launches.  Islands whose window fits the LDS of
+    a workgroup come first, by group g = max(first superblock row - 1, 0) (the order vp9hip_intra_islands_lf
+    wants); returns (island tasks, islands, wave offsets, big tasks, big wave starts, n_lds, row_pos)."""
     from cuda_vp9_amd import ISLAND_DTYPE
     n = len(tasks)
     if n == 0:
-        return (tasks, np.zeros(0, ISLAND_DTYPE), np.zeros(1, np.int32), tasks, np.zeros(1, np.int32))
+        return (tasks, np.zeros(0, ISLAND_DTYPE), np.zeros(1, np.int32), tasks, np.zeros(1, np.int32), 0,
+                np.zeros(sb_rows or 0, np.int32))
     ids, inv, counts = np.unique(comp, return_inverse=True, return_counts=True)
     big = counts[inv] > max_island_tasks
     # islands: sort by (component, level)
     idx = np.flatnonzero(~big)
     order = idx[np.lexsort((levels[idx], inv[idx]))]
     isl_tasks = tasks[order]
-    islands, wave_off = [], []
+    islands, wave_off, fits = [], [], []
     if len(order):
         c_sorted, l_sorted = inv[order], levels[order]
         starts = np.flatnonzero(np.r_[True, c_sorted[1:] != c_sorted[:-1]])
@@ -307,12 +340,21 @@ def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
             clo = int((t["x"].astype(np.int64) << sc).min()) >> 6
             chi = (int(((t["x"].astype(np.int64) + bsz) << sc).max()) - 1) >> 6
             islands.append((a, len(wave_off), len(w), rlo | (rhi << 8) | (clo << 16) | (chi << 24)))
+            fits.append(island_fits(t))
             wave_off.extend(w.tolist())
             wave_off.append(b - a)
     islands = np.array(islands, dtype=ISLAND_DTYPE) if islands else np.zeros(0, ISLAND_DTYPE)
-    # deepest islands first: one workgroup walks an island's waves in sequence, so the deepest island
-    # is the critical path of the launch (and of the loop-filter rows that wait for it)
-    islands = islands[np.argsort(-islands["n_waves"].astype(np.int64), kind="stable")]
+    fits = np.array(fits, bool)
+    # the islands of the fused launch first, by group; inside a group (and among the others) deepest first: one
+    # workgroup walks an island's waves in sequence, so the deepest island is the critical path
+    grp = np.maximum((islands["reserved"] & 255).astype(np.int64) - 1, 0)
+    key_g = np.where(fits, grp, 1 << 20)
+    islands = islands[np.lexsort((-islands["n_waves"].astype(np.int64), key_g))]
+    n_lds = int(fits.sum())
+    row_pos = None
+    if sb_rows is not None:
+        g = np.maximum((islands["reserved"][:n_lds] & 255).astype(np.int64) - 1, 0)
+        row_pos = np.cumsum(np.bincount(np.minimum(g, sb_rows - 1), minlength=sb_rows)).astype(np.int32)
     wave_off = np.array(wave_off if wave_off else [0], np.int32)
     # remainder: global waves
     idx = np.flatnonzero(big)
@@ -324,7 +366,7 @@ def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096):
         wave_start = np.searchsorted(lv, np.arange(1, nw + 2)).astype(np.int32)
     else:
         wave_start = np.zeros(1, np.int32)
-    return isl_tasks, islands, wave_off, big_tasks, wave_start
+    return isl_tasks, islands, wave_off, big_tasks, wave_start, n_lds, row_pos
 
 
 def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_frac=0.35, compound_frac=0.15,
@@ -471,7 +513,8 @@ def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_fr
     have_right = (T["x"][sel] - pbx + n_px) < pbs
     itasks["flags"] = have_top.astype(np.uint8) | (have_left.astype(np.uint8) << 1) | (have_right.astype(np.uint8) << 2)
     levels, comp = intra_levels(itasks, dims, want_components=True)
-    isl_tasks, islands, isl_wave_off, big_tasks, big_wave_start = pack_intra_islands(itasks, levels, comp)
+    isl_tasks, islands, isl_wave_off, big_tasks, big_wave_start, n_lds, row_pos = pack_intra_islands(
+        itasks, levels, comp, sb_rows=(ah + 63) >> 6)
     lo = np.argsort(levels, kind="stable")
     itasks_sorted = itasks[lo]
     n_waves = int(levels.max()) if len(levels) else 0
@@ -487,6 +530,7 @@ def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_fr
                 intra_decode_order=itasks, intra_sorted=itasks_sorted, wave_start=wave_start, n_waves=n_waves,
                 intra_island_tasks=isl_tasks, intra_islands=islands, intra_island_wave_off=isl_wave_off,
                 intra_big_tasks=big_tasks, intra_big_wave_start=big_wave_start,
-                island_sb_expected=island_sb_expected(isl_tasks, islands, sb_rows, sb_cols),
+                island_sb_expected=island_sb_expected(isl_tasks, islands, sb_rows, sb_cols, isl_wave_off, n_lds),
+                n_islands_lds=n_lds, island_row_pos=row_pos,
                 lfm=lfm, sb_rows=sb_rows, sb_cols=sb_cols, thresholds=lf_thresholds(sharpness),
                 n_blocks=nb, n_txb=nt)
