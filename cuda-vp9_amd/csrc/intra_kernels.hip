@@ -373,9 +373,8 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
 constexpr int ISL_TILE = VP9HIP_ISLAND_TILE_ELEMS;
 constexpr int ISL_TASKS = VP9HIP_ISLAND_MAX_TASKS;
 constexpr int ISL_TX32 = VP9HIP_ISLAND_MAX_TX32;
-constexpr int ISL_POOL_PITCH = 17;                       // 16x16 and smaller: 16 rows of 17 dwords per slot
-constexpr int ISL_POOL_SLOT = 16 * ISL_POOL_PITCH;       // 272
-constexpr int ISL_POOL_INTS = SLOTS * ISL_POOL_SLOT;     // 2176: also two 32x33 tiles (1088 each)
+// transform scratch: per pass 64 4x4 / 32 8x8 / 16 16x16 / 4 32x32 blocks, N rows of N + 1 dwords each
+constexpr int ISL_POOL_INTS = 16 * 16 * 17;              // 4352 (64 * 20 = 1280, 32 * 72 = 2304, 4 * 1056 = 4224)
 constexpr int ISL_MARKS = 96;
 
 struct IslandLds {
@@ -385,11 +384,23 @@ struct IslandLds {
   vp9hip_intra_task tasks[ISL_TASKS];
   int box[3][4];        // x0, y0, x1, y1 of the blocks of a plane
   int idx0[3], pitch[3];  // sample (x, y) of plane p is tile[idx0[p] + y * pitch[p] + x]
-  int n32, nmarks, bad;
-  short list32[ISL_TX32];
+  int cnt[4], fill[4];  // coded blocks per transform size; their indices, size by size, in order[]
+  int nmarks, bad;
+  short order[ISL_TASKS];
   int marks[ISL_MARKS];
   short woff[ISL_TASKS + 2];  // wave offsets (relative to the island's first task)
 };
+
+// Probe builds (-DVP9HIP_STAMPS, tools/ only): wall-clock stamps (100 MHz) of a workgroup's stages
+#ifdef VP9HIP_STAMPS
+__device__ long long g_stamps[8 * 4096];
+#define VP9HIP_STAMP(k)                                                                     \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define VP9HIP_STAMP(k) do { } while (0)
+#endif
 
 // LDS of the walk through memory (islands that do not fit)
 struct IslandMemLds {
@@ -456,19 +467,6 @@ __device__ __forceinline__ int predict_px(int mode, int bs, int r, int c, const 
 
 __device__ __forceinline__ short sat16(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
 
-template <bool HBD>
-__device__ __forceinline__ int dc_only_shift(int dc, int shift) {  // txfm::dc_only with the block size at run time
-  int out;
-  if constexpr (HBD) {
-    out = txfm::rs14_i64((txfm::i64)dc * txfm::kCos[16]);
-    out = txfm::rs14_i64((txfm::i64)out * txfm::kCos[16]);
-  } else {
-    out = txfm::rs14_i32((int)(short)dc * txfm::kCos[16]);
-    out = txfm::rs14_i32(txfm::mul32(out, txfm::kCos[16]));
-  }
-  return txfm::add32(out, 1 << (shift - 1)) >> shift;
-}
-
 // forms a coded block's residual takes (vp9_idct.c:119-204): 0 full transform, 1 DC only, 2 lossless DC only,
 // 3 the slot holds the residual itself (residual-plane mode)
 __device__ __forceinline__ int resid_kind(const vp9hip_intra_task &tk) {
@@ -487,28 +485,57 @@ __device__ __forceinline__ void store_resid_col(short *dst, int pitch, const int
   for (int k = 0; k < N; ++k) dst[k * pitch] = sat16(v[k]);
 }
 
-template <int N, bool HBD, int PITCH>
-__device__ __forceinline__ void island_full_transform(IslandLds &S, const vp9hip_intra_task &tk, int t, int *pt,
-                                                      const int32_t *__restrict__ coeffs) {
-  // t < N lanes of one wavefront; LDS of one wavefront is in order, so a fence per stage is enough (slot_sync)
-  const bool lossless = tk.tx_type & 0x80;
-  const int tt = tk.tx_type & 3;
-  if (t < N) {
+// The residual of every coded N x N block of the island: N lanes per block (lane = row in the row pass, column in
+// the column pass), 256 / N blocks per pass (16x16: 16, 32x32: 4 — one per wavefront).  A block's lanes lie inside one
+// wavefront, whose LDS operations execute in order: a fence per stage is enough (slot_sync).
+template <int N, bool HBD>
+__device__ __forceinline__ void island_residual_pass(IslandLds &S, int first, int count, const int32_t *__restrict__ coeffs) {
+  constexpr int PITCH = N + 1;
+  constexpr int BPP = N == 32 ? 4 : 256 / N;      // blocks per pass
+  constexpr int LPB = N == 32 ? 64 : N;           // lanes a block owns (32x32: a wavefront, half of it idle)
+  const int lb = (int)threadIdx.x / LPB, t = (int)threadIdx.x % LPB;
+  int *pt = S.pool + lb * N * PITCH;
+  for (int base = 0; base < count; base += BPP) {
+    const bool active = base + lb < count && t < N;
+    vp9hip_intra_task tk;
+    memset(&tk, 0, sizeof(tk));
+    if (active) tk = S.tasks[S.order[first + base + lb]];
+    const int kind = resid_kind(tk);
+    const bool lossless = tk.tx_type & 0x80;
+    const int tt = N == 32 ? 0 : (tk.tx_type & 3);
     const int32_t *src = coeffs + tk.coeff_off;
-    const int rd = txfm::coeff_rows(tk.eob, lossless ? 0 : tt, N);
+    const int pl = tk.plane, pitch = S.pitch[pl];
+    short *dst = &S.tile[S.idx0[pl] + (int)tk.y * pitch + (int)tk.x + t];
+    const bool full = active && kind == 0;
+    if (full) {
+      const int rd = txfm::coeff_rows(tk.eob, lossless ? 0 : (tk.tx_type & 3), N);
 #pragma unroll
-    for (int i = 0; i < N; ++i) pt[i * PITCH + t] = i < rd ? src[i * N + t] : 0;
+      for (int i = 0; i < N; ++i) pt[i * PITCH + t] = i < rd ? src[i * N + t] : 0;
+    } else if (active) {
+      if (kind == 3) {  // the slot holds the residual itself
+        for (int k = 0; k < N; ++k) dst[k * pitch] = sat16(src[k * N + t]);
+      } else if (kind == 1) {
+        const short a1 = sat16(txfm::dc_only<N, HBD>(src[0]));
+        for (int k = 0; k < N; ++k) dst[k * pitch] = a1;
+      } else {  // vpx_iwht4x4_1_add_c (inv_txfm.c:71-94)
+        txfm::i64 a1 = src[0] >> 2, e1 = a1 >> 1;
+        a1 -= e1;
+        const int ip = t == 0 ? (int)a1 : (int)e1;
+        const int e = ip >> 1;
+        dst[0] = sat16(ip - e);
+        dst[pitch] = dst[2 * pitch] = dst[3 * pitch] = sat16(e);
+      }
+    }
+    slot_sync();
+    if (full) row_pass<N, HBD, PITCH>(pt, t, tt, N == 4 && lossless);
+    slot_sync();
+    if (full) {
+      int v[N];
+      col_pass<N, HBD, PITCH>(pt, t, tt, N == 4 && lossless, v);
+      store_resid_col<N>(dst, pitch, v);
+    }
+    slot_sync();  // the pool tile is reused by the next pass
   }
-  slot_sync();
-  if (t < N) row_pass<N, HBD, PITCH>(pt, t, N == 32 ? 0 : tt, N == 4 && lossless);
-  slot_sync();
-  if (t < N) {
-    int v[N];
-    col_pass<N, HBD, PITCH>(pt, t, N == 32 ? 0 : tt, N == 4 && lossless, v);
-    const int pl = tk.plane;
-    store_resid_col<N>(&S.tile[S.idx0[pl] + (int)tk.y * S.pitch[pl] + (int)tk.x + t], S.pitch[pl], v);
-  }
-  slot_sync();  // the pool tile is reused by the slot's next block
 }
 
 // Returns false (workgroup-uniform) when the island does not fit: nothing was written anywhere.
@@ -523,10 +550,12 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
   const int nw = (int)isl.n_waves;
   const int n = wo[nw];
   if (n > ISL_TASKS) return false;
+  VP9HIP_STAMP(0);
   if (tid < 12) S.box[tid >> 2][tid & 3] = (tid & 2) ? 0 : 0x7fffffff;
-  if (tid == 12) S.n32 = S.nmarks = S.bad = 0;
+  if (tid >= 16 && tid < 20) S.cnt[tid - 16] = 0;
+  if (tid == 12) S.nmarks = S.bad = 0;
   __syncthreads();
-  // ---- 1. task records, wave offsets, bounding boxes, the lists of full 32x32 transforms and of completion marks
+  // ---- 1. task records, wave offsets, bounding boxes, coded blocks per transform size, completion marks
   for (int i = tid; i <= nw; i += 256) S.woff[i] = (short)wo[i];  // nw <= n <= ISL_TASKS
   for (int i = tid; i < n; i += 256) {
     const vp9hip_intra_task tk = tasks[isl.task_start + i];
@@ -537,10 +566,7 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
     atomicMax(&S.box[pl][2], (int)tk.x + bs);
     atomicMax(&S.box[pl][3], (int)tk.y + bs);
     if (tk.plane > 2 || tk.tx_size > 3 || (tk.flags & 8)) S.bad = 1;  // (raw edges: the rtcd twins' wave launches only)
-    if (coeffs != nullptr && tk.eob > 0 && tk.tx_size == 3 && resid_kind(tk) == 0) {
-      const int k = atomicAdd(&S.n32, 1);
-      if (k < ISL_TX32) S.list32[k] = (short)i;
-    }
+    if (coeffs != nullptr && tk.eob > 0) atomicAdd(&S.cnt[tk.tx_size & 3], 1);
     if (sb_done != nullptr && (tk.reserved & 1)) {
       // chroma subsampling from the plane sizes (4:2:0, 4:4:4 or single-plane frames)
       const int sx = tk.plane && f.awidth[pl] < f.awidth[0], sy = tk.plane && f.aheight[pl] < f.aheight[0];
@@ -562,90 +588,84 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
         S.pitch[p] = S.idx0[p] = 0;
       }
     }
-    if (acc > ISL_TILE || S.n32 > ISL_TX32 || S.nmarks > ISL_MARKS) S.bad = 1;
+    if (acc > ISL_TILE || S.cnt[3] > ISL_TX32 || S.nmarks > ISL_MARKS) S.bad = 1;
+    int o = 0;
+    for (int k = 0; k < 4; ++k) {
+      S.fill[k] = o;
+      o += S.cnt[k];
+    }
   }
   __syncthreads();
   if (S.bad) return false;
+  VP9HIP_STAMP(1);
   const int wave = tid >> 6, lane = tid & 63;
-  // ---- 2. the window: a wavefront per row
+  // ---- 2. the window, four samples per lane and load (aligned: block positions are multiples of 4, so is the plane's
+  // start in memory); the indices of the coded blocks, size by size, ride along
+  if (coeffs != nullptr)
+    for (int i = tid; i < n; i += 256)
+      if (S.tasks[i].eob > 0) S.order[atomicAdd(&S.fill[S.tasks[i].tx_size & 3], 1)] = (short)i;
 #pragma unroll 1
   for (int p = 0; p < 3; ++p) {
     const int *b = S.box[p];
     if (b[2] <= b[0]) continue;
     const int ox = b[0] - 1, oy = b[1] - 1, W = b[2] - b[0] + 5, H = b[3] - b[1] + 1;
+    const int qx0 = (ox < 0 ? ox - 3 : ox) / 4 * 4;            // first quad's x (floor to a multiple of 4)
+    const int nq = (ox + W - qx0 + 3) >> 2;                     // quads per row
+    const unsigned inv = ((1u << 20) + nq - 1) / nq;            // r = i / nq for i < 2^20 / nq (here i < ~4000)
     const int pitch = S.pitch[p], idx0 = S.idx0[p];
     const Pix *plane = (const Pix *)f.plane[p];
     const int stride = f.stride[p], fw = f.awidth[p], fh = f.aheight[p];
-    for (int r = wave; r < H; r += 4) {
-      const int gy = oy + r;
-      if (gy < 0 || gy >= fh) continue;
-      for (int c = lane; c < W; c += 64) {
-        const int gx = ox + c;
-        if (gx >= 0 && gx < fw) S.tile[idx0 + gy * pitch + gx] = (short)plane[(size_t)gy * stride + gx];
+    for (int i = tid; i < nq * H; i += 256) {
+      const int r = (int)(((unsigned)i * inv) >> 20), q = i - r * nq;
+      const int gy = oy + r, gx = qx0 + 4 * q;
+      if (gy < 0 || gy >= fh || gx < 0 || gx >= fw) continue;  // (the plane's width is a multiple of 8)
+      int v0, v1, v2, v3;
+      if constexpr (sizeof(Pix) == 1) {
+        const unsigned w = *(const unsigned *)(plane + (size_t)gy * stride + gx);
+        v0 = w & 255, v1 = (w >> 8) & 255, v2 = (w >> 16) & 255, v3 = w >> 24;
+      } else {
+        const uint2 w = *(const uint2 *)(plane + (size_t)gy * stride + gx);
+        v0 = w.x & 0xffff, v1 = w.x >> 16, v2 = w.y & 0xffff, v3 = w.y >> 16;
       }
+      short *d = &S.tile[idx0 + gy * pitch + gx];
+      const int lo = ox - gx, hi = ox + W - gx;  // window columns [lo, hi) of this quad
+      if (0 >= lo && 0 < hi) d[0] = (short)v0;
+      if (1 >= lo && 1 < hi) d[1] = (short)v1;
+      if (2 >= lo && 2 < hi) d[2] = (short)v2;
+      if (3 >= lo && 3 < hi) d[3] = (short)v3;
     }
   }
   __syncthreads();
-  // ---- 3. residuals: eight blocks at a time (a 32-lane slot each); full 32x32 transforms two at a time
-  const int slot = tid / SLOT, t = tid % SLOT;
+  VP9HIP_STAMP(2);
+  // ---- 3. residuals, size by size
   if (coeffs != nullptr) {
-    for (int base = 0; base < n; base += SLOTS) {
-      const int ti = base + slot;
-      vp9hip_intra_task tk;
-      memset(&tk, 0, sizeof(tk));
-      if (ti < n) tk = S.tasks[ti];
-      const bool coded = ti < n && tk.eob > 0;
-      const int kind = resid_kind(tk);
-      const int bs = 4 << tk.tx_size, pl = tk.plane;
-      int *pt = S.pool + slot * ISL_POOL_SLOT;
-      if (coded && kind != 0) {
-        if (t < bs) {
-          short *dst = &S.tile[S.idx0[pl] + (int)tk.y * S.pitch[pl] + (int)tk.x + t];
-          const int32_t *src = coeffs + tk.coeff_off;
-          const int pitch = S.pitch[pl];
-          if (kind == 3) {
-            for (int k = 0; k < bs; ++k) dst[k * pitch] = sat16(src[k * bs + t]);
-          } else if (kind == 1) {
-            const short a1 = sat16(dc_only_shift<HBD>(src[0], tk.tx_size == 0 ? 4 : (tk.tx_size == 1 ? 5 : 6)));
-            for (int k = 0; k < bs; ++k) dst[k * pitch] = a1;
-          } else {  // vpx_iwht4x4_1_add_c (inv_txfm.c:71-94)
-            txfm::i64 a1 = src[0] >> 2, e1 = a1 >> 1;
-            a1 -= e1;
-            const int ip = t == 0 ? (int)a1 : (int)e1;
-            const int e = ip >> 1;
-            dst[0] = sat16(ip - e);
-            dst[pitch] = dst[2 * pitch] = dst[3 * pitch] = sat16(e);
-          }
-        }
-      }
-      // (a wavefront holds two slots: the transforms of both run under one uniform switch per size)
-      const bool full = coded && kind == 0;
-      if (__builtin_amdgcn_ballot_w64(full && tk.tx_size == 0)) {
-        if (full && tk.tx_size == 0) island_full_transform<4, HBD, ISL_POOL_PITCH>(S, tk, t, pt, coeffs);
-      }
-      if (__builtin_amdgcn_ballot_w64(full && tk.tx_size == 1)) {
-        if (full && tk.tx_size == 1) island_full_transform<8, HBD, ISL_POOL_PITCH>(S, tk, t, pt, coeffs);
-      }
-      if (__builtin_amdgcn_ballot_w64(full && tk.tx_size == 2)) {
-        if (full && tk.tx_size == 2) island_full_transform<16, HBD, ISL_POOL_PITCH>(S, tk, t, pt, coeffs);
-      }
+    int first = 0;
+    if (S.cnt[0]) island_residual_pass<4, HBD>(S, first, S.cnt[0], coeffs);
+    first += S.cnt[0];
+    if (S.cnt[1]) {
+      __syncthreads();  // (the passes lay their tiles over the same scratch)
+      island_residual_pass<8, HBD>(S, first, S.cnt[1], coeffs);
     }
-    const int n32 = S.n32;
-    if (n32) __syncthreads();  // the two big tiles lie over the eight small ones
-    for (int j = 0; j < n32; j += 2) {
-      // wavefronts 0 and 2, lanes 0..31: one 32x33 pool tile each
-      const int q = wave >> 1;
-      if ((wave & 1) == 0 && j + q < n32 && lane < 32)
-        island_full_transform<32, HBD, 33>(S, S.tasks[S.list32[j + q]], lane, S.pool + q * (ISL_POOL_INTS / 2), coeffs);
+    first += S.cnt[1];
+    if (S.cnt[2]) {
+      __syncthreads();
+      island_residual_pass<16, HBD>(S, first, S.cnt[2], coeffs);
+    }
+    first += S.cnt[2];
+    if (S.cnt[3]) {
+      __syncthreads();
+      island_residual_pass<32, HBD>(S, first, S.cnt[3], coeffs);
     }
   }
   __syncthreads();
+  VP9HIP_STAMP(3);
   // ---- 4. the waves.  Task j of a chunk goes to wavefront j % 4 (slot 2 * (j % 4) + j / 4): most waves of a deep
   // chain have four tasks or fewer, and the two slots of a wavefront run one after the other where they differ
   const int wslot = ((tid / SLOT) & 1) * (SLOTS / 2) + (tid / SLOT) / 2;
   const int maxv = (1 << f.bit_depth) - 1;
   const int basev = 128 << (f.bit_depth - 8);
   int *E = S.edge[wslot] + EOFF;
+  const int t = tid % SLOT;
   for (int w = 0; w < nw; ++w) {
     const int begin = S.woff[w], end = S.woff[w + 1];
     for (int base = begin; base < end; base += SLOTS) {
@@ -694,19 +714,38 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
       if (active) {
         const bool coded = coeffs != nullptr && tk.eob > 0;
         short *blk = &S.tile[idx0 + y * pitch + x];
-        for (int i = t; i < bs * bs; i += SLOT) {
-          const int r = i >> lg, c = i & (bs - 1);
-          int px = predict_px(tk.mode, bs, r, c, E, dc, maxv);
-          short *d = blk + r * pitch + c;
-          if (coded) px = clip_to(px + (int)*d, maxv);
-          *d = (short)px;
+        // one loop per mode (the mode is the same for the 32 lanes of a slot): the compiler overlaps the LDS reads of
+        // consecutive samples, which it cannot do across a switch inside the loop
+#define ISL_PREDICT(MODE)                                                  \
+  for (int i = t; i < bs * bs; i += SLOT) {                                \
+    const int r = i >> lg, c = i & (bs - 1);                               \
+    int px = predict_px(MODE, bs, r, c, E, dc, maxv);                      \
+    short *d = blk + r * pitch + c;                                        \
+    if (coded) px = clip_to(px + (int)*d, maxv);                           \
+    *d = (short)px;                                                        \
+  }
+        switch (tk.mode) {
+          case 0: ISL_PREDICT(0) break;
+          case 1: ISL_PREDICT(1) break;
+          case 2: ISL_PREDICT(2) break;
+          case 3: ISL_PREDICT(3) break;
+          case 4: ISL_PREDICT(4) break;
+          case 5: ISL_PREDICT(5) break;
+          case 6: ISL_PREDICT(6) break;
+          case 7: ISL_PREDICT(7) break;
+          case 8: ISL_PREDICT(8) break;
+          case 9: ISL_PREDICT(9) break;
+          default: ISL_PREDICT(10) break;
         }
+#undef ISL_PREDICT
       }
       slot_sync();  // E is rewritten by the slot's next block
     }
     __syncthreads();
   }
+  VP9HIP_STAMP(4);
   // ---- 5. the island's blocks -> the frame: four samples per lane and store
+  const int slot = tid / SLOT;
   for (int base = 0; base < n; base += SLOTS) {
     const int ti = base + slot;
     if (ti >= n) continue;
@@ -731,6 +770,7 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
       }
     }
   }
+  VP9HIP_STAMP(5);
   if (sb_done != nullptr) {
     // Completion marks.  Producer half of the hand-off recipe (MI355X_MICROARCH.md, "Valid forms"): plain stores,
     // every storing wave's vmcnt(0) + the barrier (__syncthreads), ONE agent-scope release (writes this XCD's dirty
@@ -743,6 +783,7 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
         __hip_atomic_fetch_add(&sb_done[S.marks[k]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  VP9HIP_STAMP(6);
   return true;
 }
 

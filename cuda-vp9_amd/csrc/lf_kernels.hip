@@ -531,6 +531,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   }
   if (threadIdx.x == 0) flags[0] = 0;
   __syncthreads();
+  VP9HIP_STAMP(1);
   for (int sc = 0; sc < ncols; ++sc) {
     const int x0 = sc * n;
     const bool last = sc == ncols - 1;
@@ -658,26 +659,40 @@ __global__ __launch_bounds__(256, WALK_LF_WAVES) void walk_lf_kernel(const vp9hi
                                                       lf_granule *hand, unsigned gen, RowPos rp) {
   __shared__ WalkLfLds<Pix> S;
   const int b = (int)blockIdx.x;
-  int k = 0;  // row groups that start at or before b
-  for (int r = 0; r < sb_rows; ++r)
-    if (rp.pos[r] + r * planes <= b) k = r + 1;
+  int k = 0;  // row groups that start at or before b: pos[r] + r * planes grows with r
+  for (int hi = sb_rows; k < hi;) {
+    const int mid = (k + hi) >> 1;
+    if (rp.pos[mid] + mid * planes <= b)
+      k = mid + 1;
+    else
+      hi = mid;
+  }
   const int start = k > 0 ? rp.pos[k - 1] + (k - 1) * planes : 0;
   if (k > 0 && b < start + planes) {
     const int sr = k - 1, pl = b - start;
     if (sr == 0 && pl == 0)
       for (int i = (int)threadIdx.x; i < n_gate; i += 256) gate_next[i] = 0;
+    VP9HIP_STAMP(0);
     lf_row_entry<Pix, SH>(S.row, lfms, sb_cols, sb_rows, th, f, mi_rows, err, gate_done, gate_expected, hand, gen, sr, pl);
+    VP9HIP_STAMP(7);
     return;
   }
   const vp9hip_intra_island isl = islands[b - k * planes];
   if (!island_lds_body<Pix, sizeof(Pix) == 2>(S.isl, tasks, isl, wave_off, coeffs, f, gate_done, sb_cols)) {
-    // not an island of this launch's kind (vp9hip.h: VP9HIP_ISLAND_FITS): its marks never come, the rows around it
-    // give up after their bounded wait; say why
+    // not an island for this launch (vp9hip.h: VP9HIP_ISLAND_FITS): its marks never come, the rows around it give
+    // up after their bounded wait; say why
     if (threadIdx.x == 0) atomicOr(err, 2);
   }
 }
 
 }  // namespace
+
+#ifdef VP9HIP_STAMPS
+// probe builds only: the stamps of the last fused launch (8 per workgroup; islands 0..6, filter rows 0 and 7)
+extern "C" int vp9hip_debug_stamps(long long *out, int n_workgroups) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 8 * (size_t)n_workgroups) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // The hand-off granules of the row-walking filter (8 rows per superblock row and plane, 8 bytes per sample
 // dword) and the generation number that tags this launch's granules.

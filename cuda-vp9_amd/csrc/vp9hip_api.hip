@@ -71,8 +71,8 @@ extern "C" int vp9hip_sync(vp9hip_ctx *ctx) {
       VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(int)));  // reported once
       if (flag & 2)
         VP9HIP_FAIL(ctx, VP9HIP_EINVAL,
-                    "vp9hip_intra_islands_lf: an island does not fit the LDS window (VP9HIP_ISLAND_FITS) — such islands go to "
-                    "vp9hip_intra_pred_islands first; the frames enqueued since the last synchronisation are not valid");
+                    "vp9hip_intra_islands_lf: an island does not fit the LDS window (VP9HIP_ISLAND_FITS); the frames "
+                    "enqueued since the last synchronisation are not valid");
       VP9HIP_FAIL(ctx, VP9HIP_EDEVICE,
                   "loop filter: a superblock row gave up waiting (for the row above or for the intra islands around it); "
                   "the frames enqueued since the last synchronisation are not valid");

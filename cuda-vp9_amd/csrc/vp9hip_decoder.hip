@@ -572,9 +572,8 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
       DEC_HIP(dec, hipGetLastError());
     }
     // islands and the loop filter as one launch when both phases are asked for and nothing forces the
-    // sequence (key frames' large components; an explicit mask array that must be uploaded first is fine).
-    // Islands too wide for the LDS walk (the tail of the list) go through memory first.
-    const bool overlap = (phases & VP9HIP_PHASE_LF) && thresh && P->n_islands_lds && !P->n_intra_big_tasks && P->sb_rows <= 128 &&
+    // sequence (key frames' large components; an explicit mask array that must be uploaded first is fine)
+    const bool overlap = (phases & VP9HIP_PHASE_LF) && thresh && P->n_islands && !P->n_intra_big_tasks && P->sb_rows <= 128 &&
                          P->sb_cols <= 128 && P->island_sb_expected && P->island_row_pos && (h_lfm || P->lfm);
     if (overlap) {
       if (h_lfm) {
@@ -582,12 +581,8 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
         if (rc) return rc;
         DEC_HIP(dec, hipStreamSynchronize(st));
       }
-      if (P->n_islands > P->n_islands_lds)
-        DEC_CTX(dec, vp9hip_intra_pred_islands(dec->ctx, (const vp9hip_intra_task *)S->d_isl_tasks.p,
-                                               (const vp9hip_intra_island *)S->d_islands.p + P->n_islands_lds,
-                                               P->n_islands - P->n_islands_lds, (const int32_t *)S->d_wave_off.p, coeffs, dst));
       DEC_CTX(dec, vp9hip_intra_islands_lf(dec->ctx, (const vp9hip_intra_task *)S->d_isl_tasks.p,
-                                           (const vp9hip_intra_island *)S->d_islands.p, P->n_islands_lds,
+                                           (const vp9hip_intra_island *)S->d_islands.p, P->n_islands,
                                            (const int32_t *)S->d_wave_off.p, coeffs, (const int32_t *)S->d_sb_expected.p,
                                            P->island_row_pos, (const vp9hip_lfm *)S->d_lfm.p, P->sb_rows, P->sb_cols, thresh, dst, 3));
       phases &= ~VP9HIP_PHASE_LF;

@@ -380,12 +380,9 @@ static void counting_sort(const void *src, void *dst, size_t rec, const int32_t 
  * walk (vp9hip_intra_islands_lf) reaches superblock (r, c) after about (r + c) superblock steps and needs every
  * island around it finished by then, and an island takes its depth in waves: earliest deadline first, deadline =
  * (first row + first column) steps minus the island's own duration (a step of the filter is about 2.2 wave times
- * of the walk; measured).  In front of that: the islands that fit the LDS window before the
- * others (two lists for the frame driver), and among the former the group g = max(first superblock row - 1, 0)
- * — filter row r is placed behind the islands of groups <= r in the fused launch's grid, which are all the
- * islands that touch superblock rows <= r + 1, i.e. all it ever waits for.  Sort flags ride in the top bits of
- * n_waves while the list is sorted. */
-#define ISL_WIDE_BIT 0x80000000u
+ * of the walk; measured).  In front of that: the group g = max(first superblock row - 1, 0) —
+ * filter row r is placed behind the islands of groups <= r in the fused launch's grid, which are all the islands
+ * that touch superblock rows <= r + 1, i.e. all it ever waits for. */
 static int g_isl_w[3] = { 56, 60, 0 };
 static int island_group(const vp9hip_intra_island *x) {
   const int r = (int)(x->reserved & 255);
@@ -397,16 +394,12 @@ static int island_key(const vp9hip_intra_island *x) {
     r = r > 0 ? r - 1 : 0;
     c = c > 0 ? c - 1 : 0;
   }
-  return g_isl_w[0] * (r + c) - g_isl_w[1] * (int)(x->n_waves & ~ISL_WIDE_BIT);
+  return g_isl_w[0] * (r + c) - g_isl_w[1] * (int)x->n_waves;
 }
 static int island_deadline_first(const void *a, const void *b) {
   const vp9hip_intra_island *x = (const vp9hip_intra_island *)a, *y = (const vp9hip_intra_island *)b;
-  const unsigned wx = x->n_waves & ISL_WIDE_BIT, wy = y->n_waves & ISL_WIDE_BIT;
-  if (wx != wy) return wx ? 1 : -1;
-  if (!wx) {
-    const int gx = island_group(x), gy = island_group(y);
-    if (gx != gy) return gx < gy ? -1 : 1;
-  }
+  const int gx = island_group(x), gy = island_group(y);
+  if (gx != gy) return gx < gy ? -1 : 1;
   const int kx = island_key(x), ky = island_key(y);
   if (kx != ky) return kx < ky ? -1 : 1;
   return x->task_start < y->task_start ? -1 : (x->task_start > y->task_start);
@@ -1202,7 +1195,9 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
     }
     for (int i = 0; i < na; ++i) comp[i] = grp[comp[i]];
   }
-  /* split: islands (components that fit one workgroup's walk) / big components (global waves) */
+  /* split: islands (one workgroup walks them in its LDS: VP9HIP_ISLAND_FITS — groups were only formed while they
+   * fit, so this is about single components) / big components (global waves: key frames, large intra areas) */
+#define ISLAND_OK(c) (csize[c] <= MAX_ISLAND_TASKS && VP9HIP_ISLAND_FITS(cbox[c].box, csize[c], cbox[c].n_tx32))
   {
     vp9hip_intra_task *isl = (vp9hip_intra_task *)pk->intra_isl.p, *big = (vp9hip_intra_task *)pk->intra_big.p;
     const size_t kmax = (size_t)(max_level > n_comp ? max_level : n_comp) + 2;
@@ -1221,7 +1216,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
     out->island_sb_expected = rexp;
     /* gather, keeping decode order */
     for (int i = 0; i < na; ++i) {
-      if (csize[comp[i]] > MAX_ISLAND_TASKS) {
+      if (!ISLAND_OK(comp[i])) {
         big[n_big] = ia[i];
         k2[n_big++] = lv[i] - 1;
       }
@@ -1252,7 +1247,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
 
     /* islands: sort by (component, level) = stable by level, then stable by component */
     for (int i = 0; i < na; ++i) {
-      if (csize[comp[i]] <= MAX_ISLAND_TASKS) {
+      if (ISLAND_OK(comp[i])) {
         tmp[n_isl] = ia[i];
         k1[n_isl] = lv[i] - 1;
         k2[n_isl] = comp[i];
@@ -1274,7 +1269,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
         PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
       vp9hip_intra_island *is = (vp9hip_intra_island *)pk->islands.p;
       int32_t *wo = (int32_t *)pk->wave_off.p;
-      int n_is = 0, n_wo = 0, a = 0;
+      int n_is = 0, n_wo = 0, a = 0, n_lds = 0;
       while (a < n_isl) {
         const int c = k2[idx[a]];
         int e = a;
@@ -1315,9 +1310,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
          * bit 0 of `reserved`: when its wave is done the island is done with that superblock, and the
          * island kernel says so to the loop filter (vp9hip_intra_islands_lf); island_sb_expected counts the
          * marks per superblock.  A transform block never straddles superblocks. */
-        /* (counted for the islands of the fused launch only: the others are walked before it) */
-        const int fits = VP9HIP_ISLAND_FITS(cbox[c].box, e - a, cbox[c].n_tx32);
-        if (!fits) r->n_waves |= ISL_WIDE_BIT;
+        ++n_lds; /* every island fits: the others went to the global waves */
         for (int k = e - 1; k >= a; --k) {
           vp9hip_intra_task *t = &isl[k];
           const int sc = t->plane ? ss : 0;
@@ -1329,7 +1322,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
           if (sb_stamp[sb] != n_is) { /* n_is = 1-based id of this island */
             sb_stamp[sb] = n_is;
             t->reserved = 1;
-            if (fits) ++rexp[sb];
+            ++rexp[sb];
           }
         }
         a = e;
@@ -1342,13 +1335,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
       if (vec_reserve(&pk->row_pos, sizeof(int32_t) * (size_t)(sb_rows + 1))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");
       int32_t *rpos = (int32_t *)pk->row_pos.p;
       memset(rpos, 0, sizeof(int32_t) * (size_t)(sb_rows + 1));
-      int n_lds = 0;
       for (int k = 0; k < n_is; ++k) {
-        if (is[k].n_waves & ISL_WIDE_BIT) {
-          is[k].n_waves &= ~ISL_WIDE_BIT;
-          continue;
-        }
-        ++n_lds;
         const int g = island_group(&is[k]);
         ++rpos[g < sb_rows ? g : sb_rows - 1];
       }

@@ -49,17 +49,12 @@ class FrameJob:
             ctx.inter_pred_batch(self.d_inter, self.inter_counts, self.refs, self.dst)
         if "txb" in phases and self.d_txb is not None:
             ctx.idct_add_batch(self.d_txb, wl["txb_counts"], self.d_coeffs, self.dst)
-        # intra + loop filter of the same frame as one launch (islands walked in LDS, the filter's rows gated on
-        # the islands they depend on) unless the frame has components too large for an island (key frames) or only
-        # one of the two phases is asked for; islands too wide for the LDS window are walked through memory first
-        n_lds = wl.get("n_islands_lds", 0)
-        if ("intra" in phases and "lf" in phases and self.use_islands and self.overlap and n_lds > 0
+        # intra + loop filter of the same frame as one launch (islands walked in LDS where they fit, the filter's
+        # rows gated on the islands they depend on) unless the frame has components too large for an island (key
+        # frames) or only one of the two phases is asked for
+        if ("intra" in phases and "lf" in phases and self.use_islands and self.overlap and self.d_islands is not None
                 and self.d_big_tasks is None and wl["sb_rows"] <= 128 and wl["sb_cols"] <= 128):
-            n_all = len(wl["intra_islands"])
-            if n_all > n_lds:
-                ctx.intra_pred_islands(self.d_isl_tasks, self.d_islands.offset(16 * n_lds), n_all - n_lds, self.d_isl_woff,
-                                       self.d_coeffs, self.dst)
-            ctx.intra_islands_lf(self.d_isl_tasks, self.d_islands, n_lds, self.d_isl_woff,
+            ctx.intra_islands_lf(self.d_isl_tasks, self.d_islands, len(wl["intra_islands"]), self.d_isl_woff,
                                  self.d_coeffs, self.d_sb_expected, wl["island_row_pos"] if self.row_pos else None,
                                  self.d_lfm, wl["sb_rows"], wl["sb_cols"], self.th, self.dst, 3)
             return

@@ -198,8 +198,8 @@ typedef struct vp9hip_intra_island {
                         column << 16 | last column << 24 (needed by vp9hip_intra_islands_lf only) */
 } vp9hip_intra_island; /* 16 bytes */
 /* LDS window of an island: int16 elements in all, tasks cached in LDS, full 32x32 transforms per island */
-#define VP9HIP_ISLAND_TILE_ELEMS 8192
-#define VP9HIP_ISLAND_MAX_TASKS 384
+#define VP9HIP_ISLAND_TILE_ELEMS 20480
+#define VP9HIP_ISLAND_MAX_TASKS 768
 #define VP9HIP_ISLAND_MAX_TX32 16
 /* row pitch (elements) of a plane window whose blocks span w samples: w + 1 (left) + 4 (above-right of a 4x4
  * block), rounded up to an odd number of dwords */
@@ -250,8 +250,8 @@ int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_ro
  * filter changes), not when the whole walk is.  The hand-over is per (island, superblock): bit 0 of
  * vp9hip_intra_task.reserved marks the LAST task of its island inside a luma superblock (list order = wave
  * order), and d_sb_expected (DEVICE, sb_rows * sb_cols entries) = number of marked tasks per superblock
- * (vp9hip_pack.h fills both).  Every island must fit the LDS window (VP9HIP_ISLAND_FITS; vp9hip_pack.h lists the
- * others separately: run them with vp9hip_intra_pred_islands first); one that does not is reported by vp9hip_sync.
+ * (vp9hip_pack.h fills both).  Every island must fit the LDS window (VP9HIP_ISLAND_FITS; vp9hip_pack.h only builds
+ * such islands and sends larger components to the global waves); one that does not is reported by vp9hip_sync.
  *
  * Forward progress by construction: a workgroup only ever waits for workgroups with a LOWER index in the same
  * grid — islands wait for nothing, a filter row waits for the row above and for islands in front of it — and the

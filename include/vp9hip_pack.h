@@ -134,18 +134,18 @@ typedef struct vp9hip_packed {
    * global waves (vp9hip_intra_pred_waves); intra_decode_order is the same set in decode order */
   const vp9hip_intra_task *intra_island_tasks;
   int32_t n_intra_island_tasks;
-  /* islands[0 .. n_islands_lds): the islands whose window fits the workgroup's LDS (VP9HIP_ISLAND_FITS), in the
-   * order vp9hip_intra_islands_lf wants: by group g = max(first superblock row - 1, 0), earliest deadline first
-   * inside a group; islands[n_islands_lds .. n_islands): the others (walked through memory by
-   * vp9hip_intra_pred_islands, before the fused launch) */
+  /* the islands in the order vp9hip_intra_islands_lf wants: by group g = max(first superblock row - 1, 0),
+   * earliest deadline first inside a group.  Every island fits the LDS window of a workgroup
+   * (VP9HIP_ISLAND_FITS: small components are gathered into an island only while it does, and a component that
+   * does not fit by itself goes to the global waves below); n_islands_lds == n_islands */
   const vp9hip_intra_island *islands;
   int32_t n_islands, n_islands_lds;
   const int32_t *island_wave_off;
   int32_t n_island_wave_off;
   /* islands[i].reserved = the LUMA superblocks the island's samples lie in: first row | last row << 8 |
-   * first column << 16 | last column << 24; island_sb_expected[r * sb_cols + c] = number of LDS islands
+   * first column << 16 | last column << 24; island_sb_expected[r * sb_cols + c] = number of islands
    * that touch superblock (r, c) — what the loop filter waits for, superblock by superblock, when it
-   * runs beside the island walk (vp9hip_intra_islands_lf); island_row_pos[r] (sb_rows entries) = number of LDS
+   * runs beside the island walk (vp9hip_intra_islands_lf); island_row_pos[r] (sb_rows entries) = number of
    * islands with group <= r = the islands that go in front of filter row r in that launch's grid */
   const int32_t *island_sb_expected;
   const int32_t *island_row_pos;

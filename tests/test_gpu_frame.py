@@ -47,6 +47,13 @@ def test_frame_pipeline_matches_oracle(hip, oracle, W, H, bd, kw):
     ctx.sync()
     seq = job.download()
     assert all(np.array_equal(a, b) for a, b in zip(got, seq))
+    # ... and so does the fused launch with every island in front of the filter's rows (no h_row_pos)
+    job.overlap, job.row_pos = True, False
+    job.clear_dst()
+    job.run()
+    ctx.sync()
+    first = job.download()
+    assert all(np.array_equal(a, b) for a, b in zip(got, first))
     job.free()
     ctx.close()
 

@@ -19,8 +19,6 @@ import numpy as np
 import pytest
 
 import blockgen
-import refframe
-import workload
 
 pytestmark = pytest.mark.gpu
 
@@ -37,6 +35,8 @@ def _params(hip, W, H, bd):
 
 @pytest.mark.parametrize("W,H,bd,n_dec,rounds", [(2560, 1440, 8, 6, 40), (1280, 720, 10, 4, 60)])
 def test_decoders_in_one_process(hip, W, H, bd, n_dec, rounds):
+    import refframe
+    import workload
     rng = np.random.default_rng(77)
     dt = np.uint16 if bd > 8 else np.uint8
     dims, _ = refframe.plane_dims(W, H)

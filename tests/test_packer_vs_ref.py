@@ -256,6 +256,7 @@ def test_island_superblock_marks(hip, W, H, kw, seed):
     count = np.zeros(sb_rows * sb_cols, np.int64)
     n_lds, row_pos = L["n_islands_lds"], L["island_row_pos"]
     assert 0 < n_lds <= len(isl) and len(row_pos) == sb_rows
+    n_fit = 0
     for k, r in enumerate(isl):
         n = int(woff[r["wave_off_start"] + r["n_waves"]])
         t = tasks[r["task_start"]:r["task_start"] + n]
@@ -270,24 +271,23 @@ def test_island_superblock_marks(hip, W, H, kw, seed):
         wave_of = np.searchsorted(woff[r["wave_off_start"]:r["wave_off_start"] + r["n_waves"] + 1], np.arange(n), side="right") - 1
         for v, i in last.items():
             assert wave_of[i] == wave_of[sb == v].max()
-            if k < n_lds:  # the fused launch's islands only: the others are walked before it
-                count[v] += 1
-        # the islands of the fused launch (the first n_lds) are exactly those whose window fits the LDS of a workgroup
-        assert workload.island_fits(t) == (k < n_lds)
+            count[v] += 1
+        n_fit += workload.island_fits(t)
+    assert n_fit == n_lds  # VP9HIP_ISLAND_FITS and its mirror agree
     assert np.array_equal(count, exp)
     mine = tasks.copy()
-    assert np.array_equal(workload.island_sb_expected(mine, isl, sb_rows, sb_cols, woff, n_lds), exp)
+    assert np.array_equal(workload.island_sb_expected(mine, isl, sb_rows, sb_cols, woff), exp)
     assert np.array_equal(mine["reserved"], tasks["reserved"])
     # grid order of the fused launch: islands by group g = max(first superblock row - 1, 0); filter row r sits
     # behind row_pos[r] islands, which are all the islands that touch superblock rows <= r + 1 — a row only ever
     # waits for workgroups in front of it
-    g = np.maximum((isl["reserved"][:n_lds] & 255).astype(np.int64) - 1, 0)
+    g = np.maximum((isl["reserved"] & 255).astype(np.int64) - 1, 0)
     assert np.all(np.diff(g) >= 0)
     assert np.array_equal(row_pos, np.cumsum(np.bincount(g, minlength=sb_rows))[:sb_rows])
-    first_row = (isl["reserved"][:n_lds] & 255).astype(np.int64)
+    first_row = (isl["reserved"] & 255).astype(np.int64)
     for r in range(sb_rows):
         assert np.all(np.flatnonzero(first_row <= r + 1) < row_pos[r])
-    assert row_pos[-1] == n_lds
+    assert row_pos[-1] == len(isl)
     pk.close()
 
 

@@ -260,7 +260,7 @@ def island_pitch(w):
     return p if (p & 2) else p + 2
 
 
-ISLAND_TILE_ELEMS, ISLAND_MAX_TASKS, ISLAND_MAX_TX32 = 8192, 384, 16
+ISLAND_TILE_ELEMS, ISLAND_MAX_TASKS, ISLAND_MAX_TX32 = 20480, 768, 16
 
 
 def island_fits(t):
@@ -279,19 +279,17 @@ def island_fits(t):
     return elems <= ISLAND_TILE_ELEMS
 
 
-def island_sb_expected(isl_tasks, islands, sb_rows, sb_cols, wave_off=None, n_lds=None):
+def island_sb_expected(isl_tasks, islands, sb_rows, sb_cols, wave_off=None):
     """Marks, per island, the LAST task (list order = wave order) inside each luma superblock with bit 0 of
     `reserved` — when the island is done with that superblock the island kernel reports it to the loop filter
-    running beside it — and returns expected[r * sb_cols + c] = number of marks in superblock (r, c) by the
-    first n_lds islands (those of the fused launch; default: all) (vp9hip_intra_islands_lf; mirrors vp9hip_pack.c)."""
+    running beside it — and returns expected[r * sb_cols + c] = number of marks in superblock (r, c)
+    (vp9hip_intra_islands_lf; mirrors vp9hip_pack.c)."""
     exp = np.zeros(sb_rows * sb_cols, np.int32)
     isl_tasks["reserved"] = 0
-    if n_lds is None:
-        n_lds = len(islands)
     if wave_off is None:
         starts = np.sort(islands["task_start"].astype(np.int64)) if len(islands) else np.zeros(0, np.int64)
         end_of = dict(zip(starts.tolist(), np.r_[starts[1:], len(isl_tasks)].tolist()))
-    for k, r in enumerate(islands):
+    for r in islands:
         a = int(r["task_start"])
         b = a + int(wave_off[r["wave_off_start"] + r["n_waves"]]) if wave_off is not None else end_of[a]
         t = isl_tasks[a:b]
@@ -303,23 +301,26 @@ def island_sb_expected(isl_tasks, islands, sb_rows, sb_cols, wave_off=None, n_ld
         _, first_in_rev = np.unique(rev, return_index=True)
         last = len(sb) - 1 - first_in_rev
         isl_tasks["reserved"][a + last] = 1
-        if k < n_lds:
-            np.add.at(exp, sb[last], 1)
+        np.add.at(exp, sb[last], 1)
     return exp
 
 
 def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096, sb_rows=None):
     """Split the intra tasks into islands (one workgroup each, vp9hip_intra_pred_islands) and a
-    remainder of very large components that keeps the per-wave launches.  Islands whose window fits the LDS of
-    a workgroup come first, by group g = max(first superblock row - 1, 0) (the order vp9hip_intra_islands_lf
-    wants); returns (island tasks, islands, wave offsets, big tasks, big wave starts, n_lds, row_pos)."""
+    remainder of very large components (too many blocks, or a sample window that does not fit the LDS of a
+    workgroup) that keeps the per-wave launches.  Islands are ordered by group g = max(first superblock row - 1, 0)
+    (the order vp9hip_intra_islands_lf wants); n_lds = all of them; returns (island tasks, islands, wave offsets, big tasks, big wave starts, n_lds, row_pos)."""
     from cuda_vp9_amd import ISLAND_DTYPE
     n = len(tasks)
     if n == 0:
         return (tasks, np.zeros(0, ISLAND_DTYPE), np.zeros(1, np.int32), tasks, np.zeros(1, np.int32), 0,
                 np.zeros(sb_rows or 0, np.int32))
     ids, inv, counts = np.unique(comp, return_inverse=True, return_counts=True)
-    big = counts[inv] > max_island_tasks
+    # components that do not fit the LDS window of a workgroup (VP9HIP_ISLAND_FITS) go to the global waves too
+    by_comp = np.argsort(inv, kind="stable")
+    ends_c = np.cumsum(counts)
+    fit_c = np.array([island_fits(tasks[by_comp[e - c:e]]) for c, e in zip(counts, ends_c)], bool)
+    big = (counts[inv] > max_island_tasks) | ~fit_c[inv]
     # islands: sort by (component, level)
     idx = np.flatnonzero(~big)
     order = idx[np.lexsort((levels[idx], inv[idx]))]
@@ -345,15 +346,14 @@ def pack_intra_islands(tasks, levels, comp, max_island_tasks=4096, sb_rows=None)
             wave_off.append(b - a)
     islands = np.array(islands, dtype=ISLAND_DTYPE) if islands else np.zeros(0, ISLAND_DTYPE)
     fits = np.array(fits, bool)
-    # the islands of the fused launch first, by group; inside a group (and among the others) deepest first: one
-    # workgroup walks an island's waves in sequence, so the deepest island is the critical path
+    # by group (the order vp9hip_intra_islands_lf wants); inside a group deepest first: one workgroup walks an
+    # island's waves in sequence, so the deepest island is the critical path
     grp = np.maximum((islands["reserved"] & 255).astype(np.int64) - 1, 0)
-    key_g = np.where(fits, grp, 1 << 20)
-    islands = islands[np.lexsort((-islands["n_waves"].astype(np.int64), key_g))]
+    islands = islands[np.lexsort((-islands["n_waves"].astype(np.int64), grp))]
     n_lds = int(fits.sum())
     row_pos = None
     if sb_rows is not None:
-        g = np.maximum((islands["reserved"][:n_lds] & 255).astype(np.int64) - 1, 0)
+        g = np.maximum((islands["reserved"] & 255).astype(np.int64) - 1, 0)
         row_pos = np.cumsum(np.bincount(np.minimum(g, sb_rows - 1), minlength=sb_rows)).astype(np.int32)
     wave_off = np.array(wave_off if wave_off else [0], np.int32)
     # remainder: global waves
@@ -530,7 +530,7 @@ def make_frame_workload(width, height, seed=1440, bd=8, intra_frac=0.08, skip_fr
                 intra_decode_order=itasks, intra_sorted=itasks_sorted, wave_start=wave_start, n_waves=n_waves,
                 intra_island_tasks=isl_tasks, intra_islands=islands, intra_island_wave_off=isl_wave_off,
                 intra_big_tasks=big_tasks, intra_big_wave_start=big_wave_start,
-                island_sb_expected=island_sb_expected(isl_tasks, islands, sb_rows, sb_cols, isl_wave_off, n_lds),
+                island_sb_expected=island_sb_expected(isl_tasks, islands, sb_rows, sb_cols, isl_wave_off),
                 n_islands_lds=n_lds, island_row_pos=row_pos,
                 lfm=lfm, sb_rows=sb_rows, sb_cols=sb_cols, thresholds=lf_thresholds(sharpness),
                 n_blocks=nb, n_txb=nt)
