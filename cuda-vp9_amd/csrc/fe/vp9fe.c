@@ -227,7 +227,8 @@ struct vp9hip_fe {
   int seg_cur;
   size_t seg_cap;
   MvRef *mvs[2];
-  int mv_cur, mv_rows[2], mv_cols[2];
+  int mv_cur, mv_rows[2], mv_cols[2]; /* allocated size of the two arrays */
+  int mv_wr_rows[2], mv_wr_cols[2];    /* size of the frame that last wrote each (row pitch = its mi_cols) */
   size_t mv_cap[2];
 
   /* per frame */
@@ -247,9 +248,7 @@ struct vp9hip_fe {
   vp9hip_block *out_blocks;     /* merged list (several tile columns) */
   uint32_t *out_off;
   int32_t *eob[3];
-  size_t eob_cap[3];
   int32_t *coef[3];
-  size_t coef_cap[3];
   /* the output arrays above are aliases of one of three sets used in rotation: a caller may still be packing frame
    * N - 1 and the device fetching the coefficients of frame N - 2 while frame N is parsed */
   struct OutSet {
@@ -257,6 +256,7 @@ struct vp9hip_fe {
     uint32_t (*seg_off)[3];
     uint32_t *out_off;
     int32_t *eob[3], *coef[3];
+    size_t cells_cap, eob_cap[3], coef_cap[3]; /* of THIS set: a set only grows when its own turn comes (see ensure_frame_arrays) */
     vp9hip_coeff_region regions[3 * MAX_TILE_COLS];
   } sets[3];
   int set_idx;
@@ -2024,17 +2024,21 @@ int vp9hip_fe_create(vp9hip_fe **out, vp9hip_alloc_fn alloc, vp9hip_free_fn rele
   return VP9HIP_OK;
 }
 
-static void coef_free(vp9hip_fe *fe, int p) {
-  for (int k = 0; k < 3; ++k) {
-    if (!fe->sets[k].coef[p]) continue;
+static void coef_free_set(vp9hip_fe *fe, int k, int p) {
+  struct OutSet *s = &fe->sets[k];
+  if (s->coef[p]) {
     if (fe->release)
-      fe->release(fe->user, fe->sets[k].coef[p]);
+      fe->release(fe->user, s->coef[p]);
     else
-      free(fe->sets[k].coef[p]);
-    fe->sets[k].coef[p] = NULL;
+      free(s->coef[p]);
   }
+  s->coef[p] = NULL;
+  s->coef_cap[p] = 0;
+}
+
+static void coef_free(vp9hip_fe *fe, int p) {
+  for (int k = 0; k < 3; ++k) coef_free_set(fe, k, p);
   fe->coef[p] = NULL;
-  fe->coef_cap[p] = 0;
 }
 
 static void use_set(vp9hip_fe *fe, int k) {
@@ -2125,55 +2129,53 @@ static int ensure_frame_arrays(vp9hip_fe *fe) {
     if (!fe->above_part) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
     fe->ctx_cols = ctx_cols;
   }
+  /* The three output sets rotate: the one written now was handed out three frames ago, and vp9hip_fe.h promises a
+   * frame's arrays for that call and the next two — the caller may still be packing the frame before this one and
+   * the device still fetching the coefficients of the one before that.  So only THIS set may grow: a frame larger
+   * than any before it (a key frame, an intra-only frame or a reference of another size in mid-stream) leaves the
+   * other two sets, and whatever still reads them, alone; each set catches up when its own turn comes. */
+  struct OutSet *s = &fe->sets[(fe->set_idx + 1) % 3];
+  if (cells > s->cells_cap) {
+    free(s->seg_blocks);
+    free(s->seg_off);
+    free(s->out_blocks);
+    free(s->out_off);
+    s->seg_blocks = (vp9hip_block *)malloc(sizeof(vp9hip_block) * (cells + 1));
+    s->seg_off = (uint32_t(*)[3])malloc(sizeof(uint32_t) * 3 * (cells + 1));
+    s->out_blocks = (vp9hip_block *)malloc(sizeof(vp9hip_block) * (cells + 1));
+    s->out_off = (uint32_t *)malloc(sizeof(uint32_t) * 3 * (cells + 1));
+    s->cells_cap = (s->seg_blocks && s->seg_off && s->out_blocks && s->out_off) ? cells : 0;
+    if (!s->cells_cap) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
+  }
+  /* scratch of the parse itself (not handed out) */
   if (cells > fe->cells_cap) {
-    int ok = 1;
-    for (int k = 0; k < 3; ++k) {
-      struct OutSet *s = &fe->sets[k];
-      free(s->seg_blocks);
-      free(s->seg_off);
-      free(s->out_blocks);
-      free(s->out_off);
-      s->seg_blocks = (vp9hip_block *)malloc(sizeof(vp9hip_block) * (cells + 1));
-      s->seg_off = (uint32_t(*)[3])malloc(sizeof(uint32_t) * 3 * (cells + 1));
-      s->out_blocks = (vp9hip_block *)malloc(sizeof(vp9hip_block) * (cells + 1));
-      s->out_off = (uint32_t *)malloc(sizeof(uint32_t) * 3 * (cells + 1));
-      ok &= s->seg_blocks && s->seg_off && s->out_blocks && s->out_off;
-    }
     free(fe->grid);
-    free(fe->sb_count);
     fe->grid = (int32_t *)malloc(sizeof(int32_t) * (cells + 1));
-    fe->sb_count = (int32_t *)malloc(sizeof(int32_t) * ((size_t)(ctx_cols >> 3) * (ctx_rows >> 3) + 1));
-    fe->cells_cap = (ok && fe->grid && fe->sb_count) ? cells : 0;
+    fe->cells_cap = fe->grid ? cells : 0;
     if (!fe->cells_cap) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
-  } else if ((size_t)(ctx_cols >> 3) * (ctx_rows >> 3) > fe->sb_cap) {
+  }
+  if ((size_t)(ctx_cols >> 3) * (ctx_rows >> 3) > fe->sb_cap || !fe->sb_count) {
     free(fe->sb_count);
+    fe->sb_cap = 0;
     fe->sb_count = (int32_t *)malloc(sizeof(int32_t) * ((size_t)(ctx_cols >> 3) * (ctx_rows >> 3) + 1));
     if (!fe->sb_count) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
+    fe->sb_cap = (size_t)(ctx_cols >> 3) * (ctx_rows >> 3);
   }
-  if ((size_t)(ctx_cols >> 3) * (ctx_rows >> 3) > fe->sb_cap) fe->sb_cap = (size_t)(ctx_cols >> 3) * (ctx_rows >> 3);
   for (int p = 0; p < 3; ++p) {
     const int ss = p ? fe->ss_x : 0;
     const size_t pw = (size_t)(ctx_cols * 8) >> ss, ph = (size_t)(ctx_rows * 8) >> ss;
     const size_t want_e = (pw >> 2) * (ph >> 2), want_c = pw * ph + 64;
-    if (want_e > fe->eob_cap[p]) {
-      int ok = 1;
-      for (int k = 0; k < 3; ++k) {
-        free(fe->sets[k].eob[p]);
-        fe->sets[k].eob[p] = (int32_t *)malloc(sizeof(int32_t) * want_e);
-        ok &= fe->sets[k].eob[p] != NULL;
-      }
-      fe->eob_cap[p] = ok ? want_e : 0;
-      if (!ok) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
+    if (want_e > s->eob_cap[p]) {
+      free(s->eob[p]);
+      s->eob[p] = (int32_t *)malloc(sizeof(int32_t) * want_e);
+      s->eob_cap[p] = s->eob[p] ? want_e : 0;
+      if (!s->eob[p]) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
     }
-    if (want_c > fe->coef_cap[p]) {
-      int ok = 1;
-      coef_free(fe, p);
-      for (int k = 0; k < 3; ++k) {
-        fe->sets[k].coef[p] = (int32_t *)(fe->alloc ? fe->alloc(fe->user, sizeof(int32_t) * want_c) : malloc(sizeof(int32_t) * want_c));
-        ok &= fe->sets[k].coef[p] != NULL;
-      }
-      fe->coef_cap[p] = ok ? want_c : 0;
-      if (!ok) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
+    if (want_c > s->coef_cap[p]) {
+      coef_free_set(fe, (int)(s - fe->sets), p);
+      s->coef[p] = (int32_t *)(fe->alloc ? fe->alloc(fe->user, sizeof(int32_t) * want_c) : malloc(sizeof(int32_t) * want_c));
+      s->coef_cap[p] = s->coef[p] ? want_c : 0;
+      if (!s->coef[p]) return fe_fail(fe, VP9HIP_ENOMEM, "out of memory");
     }
   }
   use_set(fe, (fe->set_idx + 1) % 3);
@@ -2212,7 +2214,9 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
   /* vp9_decode_frame :3507 */
   fe->use_prev_mvs = !h->error_res && fe->width == fe->last_width && fe->height == fe->last_height && !fe->last_intra_only &&
                      fe->last_show_frame && fe->last_frame_type != KEY_FRAME && fe->have_frame && fe->mvs[fe->mv_cur ^ 1] &&
-                     fe->mv_rows[fe->mv_cur ^ 1] == fe->mi_rows && fe->mv_cols[fe->mv_cur ^ 1] == fe->mi_cols;
+                     /* (implied by the size test above; the arrays themselves only ever grow, so their allocated size
+                      * says nothing — it kept the previous frame's vectors out after a switch to a smaller size) */
+                     fe->mv_wr_rows[fe->mv_cur ^ 1] == fe->mi_rows && fe->mv_wr_cols[fe->mv_cur ^ 1] == fe->mi_cols;
   fe->fc = fe->saved[h->frame_context_idx];
   if (!fe->fc.initialized) FE_FAIL(fe, "uninitialized entropy context");
   if ((rc = read_compressed_header(fe, data + h->header_bytes, h->first_partition_size))) return rc;
@@ -2354,6 +2358,8 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
 
   /* stream state for the next frame (vp9_receive_compressed_data :473-488) */
   fe->last_show_frame = h->show_frame;
+  fe->mv_wr_rows[fe->mv_cur] = fe->mi_rows;
+  fe->mv_wr_cols[fe->mv_cur] = fe->mi_cols;
   fe->mv_cur ^= 1;
   if (fe->seg.enabled) fe->seg_cur ^= 1;
   fe->last_width = fe->width;
@@ -2393,7 +2399,7 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
     L->eob[p] = fe->eob[p];
     L->eob_stride[p] = ((fe->ctx_cols * 8) >> ss) >> 2;
     L->plane_base[p] = base;
-    base += (int64_t)fe->coef_cap[p];
+    base += (int64_t)fe->sets[fe->set_idx].coef_cap[p];
     out->dqcoeff[p] = fe->coef[p];
   }
   L->eob_shift = 2;

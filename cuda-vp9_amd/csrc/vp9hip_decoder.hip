@@ -289,7 +289,15 @@ extern "C" int vp9hip_decoder_download_after(vp9hip_decoder *dec, int slot, cons
     DEC_HIP(dec, hipMemcpy2DAsync(dst->plane[p], (size_t)dst->stride[p] * bps, s->f.plane[p], (size_t)s->f.stride[p] * bps,
                                   (size_t)s->f.awidth[p] * bps, s->f.aheight[p], hipMemcpyDeviceToHost, dec->dl_stream));
   }
+  // a frame whose loop filter gave up waiting is never delivered: the flag is read on the download stream, behind the
+  // run's `done` event like the planes (vp9hip_sync reports and clears it at the caller's next synchronisation)
+  int lf_err = 0;
+  if (dec->ctx->lf_err_flag)
+    DEC_HIP(dec, hipMemcpyAsync(&lf_err, dec->ctx->lf_err_flag, sizeof(int), hipMemcpyDeviceToHost, dec->dl_stream));
   DEC_HIP(dec, hipStreamSynchronize(dec->dl_stream));
+  if (lf_err)
+    DEC_FAIL(dec, VP9HIP_EDEVICE, "vp9hip_decoder_download_after: the frame's loop filter gave up waiting (flag %d); the frame is not valid",
+             lf_err);
   return VP9HIP_OK;
 }
 

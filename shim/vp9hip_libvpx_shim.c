@@ -91,7 +91,8 @@ static pthread_mutex_t g_state_lock = PTHREAD_MUTEX_INITIALIZER;
 static double now_s(void);
 
 /* VP9HIP_SHIM_TRACE=1: where the time of the two entry points goes, summed over the stream and printed
- * at exit (seconds of host wall time; "kernels" are waits for the GPU) */
+ * at exit (seconds of host wall time; "kernels" are waits for the GPU).  A measurement aid for ONE decoder per
+ * process: the counters are process-wide and not synchronised — with several decoder threads the sums mix. */
 static struct {
   int on, frames;
   double gather, pack_upload, refs, inter_wait, masks, intra_wait, download;
@@ -222,6 +223,10 @@ static struct {
   void (*fn)(void *, int);
   void *arg;
 } g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
+/* One run at a time: the pool holds ONE job record (fn, arg, next, pending), and decoder threads of one process —
+ * one per GPU — enter here concurrently; a second run started while the first is in flight would overwrite it.
+ * Held for the whole call; g_pool.mu is released while an item runs. */
+static pthread_mutex_t g_pool_run = PTHREAD_MUTEX_INITIALIZER;
 
 static void *pool_worker(void *unused) {
   unsigned seen = 0;
@@ -250,6 +255,7 @@ void vp9hip_shim_run_parallel(struct VP9Decoder *pbi, int n, void (*fn)(void *ar
   const char *e = getenv("VP9HIP_SHIM_THREADS");
   if (e && atoi(e) - 1 < want) want = atoi(e) - 1;
   if (want > SHIM_POOL_MAX) want = SHIM_POOL_MAX;
+  pthread_mutex_lock(&g_pool_run);
   pthread_mutex_lock(&g_pool.mu);
   while (g_pool.n_threads < want) {
     if (pthread_create(&g_pool.th[g_pool.n_threads], NULL, pool_worker, NULL)) break;
@@ -257,6 +263,7 @@ void vp9hip_shim_run_parallel(struct VP9Decoder *pbi, int n, void (*fn)(void *ar
   }
   if (g_pool.n_threads == 0 || want <= 0) {
     pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_pool_run);
     for (int i = 0; i < n; ++i) fn(arg, i);
     return;
   }
@@ -277,6 +284,7 @@ void vp9hip_shim_run_parallel(struct VP9Decoder *pbi, int n, void (*fn)(void *ar
   }
   while (g_pool.pending) pthread_cond_wait(&g_pool.done, &g_pool.mu);
   pthread_mutex_unlock(&g_pool.mu);
+  pthread_mutex_unlock(&g_pool_run);
 }
 
 uint32_t *vp9hip_shim_block_off_buffer(struct VP9Decoder *pbi, int n_blocks) {
@@ -502,9 +510,10 @@ static int begin_frame(shim_state *s, VP9_COMMON *cm, VP9Decoder *pbi, int *size
     if (s->tile_layout_blocks >= 0) {
       /* the entropy stage ran one thread per tile column: slots are consecutive per tile (E10) */
       if (s->tile_layout_blocks != n) {
+        const int described = s->tile_layout_blocks;
         s->tile_layout_blocks = -1;
         vpx_internal_error(&cm->error, VPX_CODEC_ERROR, "vp9hip shim: tile layout describes %d blocks, the list has %d",
-                           s->tile_layout_blocks, n);
+                           described, n);
         return -1;
       }
       L.block_off = s->block_off;
