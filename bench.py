@@ -18,6 +18,10 @@ BASELINE.json's configs[1] (Bravia.1440.ivf) is not in the reference snapshot; S
                    synthesized S-1440 IVF end to end (CPU entropy decode included), beside the same vpxdec with
                    the CPU wrap_cuda_* bodies; per-frame MD5s checked
   cpu_baseline     the same frames through the REFERENCE's own C functions (oracle/_ref, ref_recon_frame)
+  decode_fps       top level, beside `value`: a real bitstream (S-1440) decoded END TO END by cuda-vp9_amd/vp9hip_dec (own
+                   front-end on the CPU + this path on the GPU, every shown frame fetched to the host), and
+                   decode_fps_vpxdec the same through the reference's vpxdec on the shim — `value` is the GPU-side ceiling
+                   of the hot path with everything resident, these are what a caller gets
 
 `python bench.py --gpus N` starts N ranks itself (one process per GPU, torch.distributed over RCCL, no
 data-path collective: independent streams, one per rank); under `torch.distributed.run` (RANK set) it is a
@@ -45,7 +49,10 @@ KERNEL_SOURCES = {"convolve": ["inter_kernels.hip"], "idct_add": ["txfm_kernels.
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=400,
+                    help="timed steps; raised (and reported as run) when they would take less than --min-seconds")
+    ap.add_argument("--min-seconds", type=float, default=0.2, help="shortest timed region")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 --pmc child runs")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=2560)
     ap.add_argument("--height", type=int, default=1440)
@@ -228,6 +235,56 @@ def real_stream_resident(hip, ivf, replay=(7, 14, 21, 28, 35, 42, 49, 56), reps=
     return {"frames_per_s": round(hm, 1), "frames": [{"index": i, "blocks": n, "filter_level": l, "frames_per_s": round(r, 1)} for i, n, l, r in rates],
             "note": "frames of the S-1440 stream as vp9hip_fe parsed them, packed by vp9hip_pack_frame, lists + coefficients resident, "
                     "vp9hip_decoder_run replayed %d times each (harmonic mean)" % reps}
+
+
+def stream_pair(name, threads=None):
+    """One BASELINE-sized stream through cuda-vp9_amd/vp9hip_dec (frames fetched) and the reference's CPU path, MD5 checked."""
+    big = os.path.join(ROOT, "tests", "streams_big")
+    ivf, gold = os.path.join(big, name + ".ivf"), os.path.join(big, name + ".md5")
+    cdec = os.path.join(ROOT, "oracle", "_ref", "vpx", "vpxdec_c")
+    if not (os.path.exists(ivf) and os.path.exists(gold) and os.path.exists(os.path.join(ROOT, "cuda-vp9_amd", "vp9hip_dec"))):
+        return {"skipped": f"tests/streams_big/{name}.ivf or vp9hip_dec absent"}
+    want = [l.rstrip("\n") for l in open(gold) if l.strip()]
+    runs = run_own_dec(ivf, loops=5)
+    out = {"frames": len(want), "vp9hip_dec_fps": round(sum(f for _, f in runs[1:]) / max(1, len(runs[1:])), 2),
+           "md5_match": run_own_dec(ivf, md5=True) == want}
+    if os.path.exists(cdec):
+        out["vpxdec_c_fps"] = run_vpxdec(cdec, ivf, loops=1)[0][1]
+    return out
+
+
+def measure_traffic(kernel_key):
+    """HBM bytes per launch of one kernel family from two rocprofv3 --pmc child runs (FETCH_SIZE and WRITE_SIZE do
+    not fit one pass on gfx950; FETCH_SIZE tallies a 128-byte request as 64 bytes: doubled, MI355X_MICROARCH.md
+    "HBM") of tools/profile_phase.py on the same frame.  None when rocprofv3 is absent or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            # the interpreter itself after `--`: rocprofv3's preloaded library has initialised the GPU before the program starts
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "profile_phase.py"), "--separate", "--steps", "4"]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240, cwd="/tmp",
+                                   env=dict(os.environ, TMPDIR="/tmp"))
+            except (subprocess.TimeoutExpired, OSError) as e:
+                return None, f"rocprofv3 --pmc {ctr}: {e}"
+            if r.returncode:
+                return None, f"rocprofv3 --pmc {ctr} failed ({r.returncode})"
+            per = {}
+            for f in glob.glob(os.path.join(tmp, ctr, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_key in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None, f"no {kernel_key} dispatch in the {ctr} pass"
+            vals[ctr] = sum(per.values()) / len(per)
+    return int(vals["FETCH_SIZE"] * 2048 + vals["WRITE_SIZE"] * 1024), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of tools/profile_phase.py, this box, this build (FETCH_SIZE x 2 on gfx950)"
 
 
 def stream_leg():

@@ -394,11 +394,14 @@ struct IslandLds {
 // Probe builds (-DVP9HIP_STAMPS, tools/ only): wall-clock stamps (100 MHz) of a workgroup's stages
 #ifdef VP9HIP_STAMPS
 __device__ long long g_stamps[8 * 4096];
+__shared__ int s_stamp_slot;  // the workgroup's place in the launch's order (its ticket)
+#define VP9HIP_STAMP_SLOT(t) (s_stamp_slot = (t))
 #define VP9HIP_STAMP(k)                                                                     \
   do {                                                                                      \
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); \
+    if (threadIdx.x == 0 && s_stamp_slot < 4096) g_stamps[s_stamp_slot * 8 + (k)] = wall_clock64(); \
   } while (0)
 #else
+#define VP9HIP_STAMP_SLOT(t) do { } while (0)
 #define VP9HIP_STAMP(k) do { } while (0)
 #endif
 
@@ -830,6 +833,7 @@ __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_ta
                                                            const int32_t *__restrict__ wave_off,
                                                            const int32_t *__restrict__ coeffs, FrameDev f) {
   __shared__ IslandAnyLds S;
+  if (threadIdx.x == 0) VP9HIP_STAMP_SLOT((int)blockIdx.x);
   const vp9hip_intra_island isl = islands[blockIdx.x];
   if (island_lds_body<Pix, HBD>(S.lds, tasks, isl, wave_off, coeffs, f, nullptr, 0)) return;
   __syncthreads();

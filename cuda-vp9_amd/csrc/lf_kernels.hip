@@ -615,13 +615,33 @@ __device__ __forceinline__ void lf_row_entry(LfRowLds<Pix> &L, const vp9hip_lfm 
                               sb_rows, hand, gen);
 }
 
-// The filter alone: workgroup (r, plane).  Row r waits for row r-1 = a workgroup with a lower index in the grid.
+// Forward progress.  A workgroup's place in the launch's ORDER is not its hardware index but a ticket it draws when it
+// starts running (one atomic add on a per-launch counter): whoever holds a lower ticket is running or done.  The
+// launches below are built so that a workgroup only ever waits for lower tickets — then every wait ends, whatever the
+// hardware's dispatch order is (the workgroups of a grid are dealt round-robin to the 8 XCDs and every XCD starts its
+// share as ITS slots allow: index order holds per XCD only, and rows resident on one XCD, waiting for islands queued
+// on another that is full of rows waiting the other way round, were seen to give up with six decoders in flight) and
+// whatever else shares the GPU: no workgroup waits for one that is not resident.
+__device__ __forceinline__ int draw_ticket(int *ticket, int *ticket_next) {
+  __shared__ int s_ticket;
+  if (threadIdx.x == 0) {
+    const int t = atomicAdd(ticket, 1);
+    if (t == 0) *ticket_next = 0;  // the next launch's counter (launches of a context run one after the other)
+    s_ticket = t;
+    VP9HIP_STAMP_SLOT(t);
+  }
+  __syncthreads();
+  return s_ticket;
+}
+
+// The filter alone: ticket t is (row t / planes, plane t % planes).  Row r waits for row r-1 = a lower ticket.
 template <typename Pix, int SH>
 __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                                        int planes, LfThreshDev th, FrameDev f, int mi_rows, int *err,
-                                                       lf_granule *hand, unsigned gen) {
+                                                       lf_granule *hand, unsigned gen, int *ticket, int *ticket_next) {
   __shared__ LfRowLds<Pix> L;
-  const int sr = (int)blockIdx.x / planes, pl = (int)blockIdx.x % planes;
+  const int b = draw_ticket(ticket, ticket_next);
+  const int sr = b / planes, pl = b % planes;
   lf_row_entry<Pix, SH>(L, lfms, sb_cols, sb_rows, th, f, mi_rows, err, nullptr, nullptr, hand, gen, sr, pl);
 }
 
@@ -639,11 +659,10 @@ union WalkLfLds {
 };
 
 // The island walk and the loop filter of a frame as ONE launch: a workgroup per island (walked in LDS) and a
-// workgroup per (superblock row, plane) of the filter, the latter placed in the grid right behind the last island
-// they can ever wait for (RowPos).  Forward progress by construction: islands wait for nothing; a row waits for the
-// row above (placed before it) and for island marks of superblock rows r, r + 1 (all in front of it); the hardware
-// starts a grid's workgroups in index order, so whoever is waited for is running or done — whatever else shares
-// the GPU.  No second stream, no fork / join events, no residual pre-pass: every dependency packet between two
+// workgroup per (superblock row, plane) of the filter, the latter placed in the launch's order (tickets, above) right
+// behind the last island they can ever wait for (RowPos).  Forward progress by construction: islands wait for
+// nothing; a row waits for the row above (placed before it) and for island marks of superblock rows r, r + 1 (all in
+// front of it).  No second stream, no fork / join events, no residual pre-pass: every dependency packet between two
 // kernels cost the command processor several microseconds (rocprofv3 trace of bench.py).
 // While the frame runs, the first row's workgroup also zero-fills the island counters of the NEXT launch.
 template <typename Pix, int SH>
@@ -656,9 +675,10 @@ __global__ __launch_bounds__(256, WALK_LF_WAVES) void walk_lf_kernel(const vp9hi
                                                       const vp9hip_intra_task *__restrict__ tasks,
                                                       const vp9hip_intra_island *__restrict__ islands,
                                                       const int32_t *__restrict__ wave_off, const int32_t *__restrict__ coeffs,
-                                                      lf_granule *hand, unsigned gen, RowPos rp) {
+                                                      lf_granule *hand, unsigned gen, RowPos rp, int *ticket,
+                                                      int *ticket_next) {
   __shared__ WalkLfLds<Pix> S;
-  const int b = (int)blockIdx.x;
+  const int b = draw_ticket(ticket, ticket_next);
   int k = 0;  // row groups that start at or before b: pos[r] + r * planes grows with r
   for (int hi = sb_rows; k < hi;) {
     const int mid = (k + hi) >> 1;
@@ -717,6 +737,19 @@ static int lf_handoff_buffer(vp9hip_ctx *ctx, const vp9hip_frame *frame, int sb_
   return VP9HIP_OK;
 }
 
+// The ticket counters of two consecutive launches (see draw_ticket): a launch counts in one and clears the other.
+static int lf_tickets(vp9hip_ctx *ctx, int **cur, int **nxt) {
+  if (!ctx->lf_ticket) {
+    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_ticket, 2 * sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_ticket, 0, 2 * sizeof(int)));
+    ctx->lf_ticket_parity = 0;
+  }
+  *cur = ctx->lf_ticket + ctx->lf_ticket_parity;
+  *nxt = ctx->lf_ticket + (ctx->lf_ticket_parity ^ 1);
+  ctx->lf_ticket_parity ^= 1;
+  return VP9HIP_OK;
+}
+
 // Argument checks + error flag + hand-off buffer shared by the two launches.
 static int lf_prepare(vp9hip_ctx *ctx, const char *who, const vp9hip_lfm *d_lfm, int sb_rows, int sb_cols,
                       const vp9hip_lf_thresh *h_thresh, const vp9hip_frame *frame, int planes, unsigned *gen) {
@@ -749,9 +782,12 @@ extern "C" int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm
   LfThreshDev th;
   memcpy(&th, h_thresh, sizeof(th));
   const FrameDev f = to_dev(frame);
+  int *ticket = nullptr, *ticket_next = nullptr;
+  rc = lf_tickets(ctx, &ticket, &ticket_next);
+  if (rc) return rc;
 #define LF_ROWS2(PIX, SH)                                                                                               \
   hipLaunchKernelGGL((lf_rows2_kernel<PIX, SH>), dim3(sb_rows * planes), dim3(256), 0, ctx->stream, d_lfm, sb_cols, sb_rows, \
-                     planes, th, f, frame->aheight[0] / 8, ctx->lf_err_flag, (lf_granule *)ctx->lf_hand, gen)
+                     planes, th, f, frame->aheight[0] / 8, ctx->lf_err_flag, (lf_granule *)ctx->lf_hand, gen, ticket, ticket_next)
   if (!frame->hbd)
     LF_ROWS2(uint8_t, 0);
   else if (frame->bit_depth == 10)
@@ -813,10 +849,13 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
   memcpy(&th, h_thresh, sizeof(th));
   const FrameDev f = to_dev(frame);
   const int grid = sb_rows * planes + n_islands;
+  int *ticket = nullptr, *ticket_next = nullptr;
+  rc = lf_tickets(ctx, &ticket, &ticket_next);
+  if (rc) return rc;
 #define WALK_LF(PIX, SH)                                                                                              \
   hipLaunchKernelGGL((walk_lf_kernel<PIX, SH>), dim3(grid), dim3(256), 0, ctx->stream, d_lfm, sb_cols, sb_rows, planes, th, f, \
                      frame->aheight[0] / 8, ctx->lf_err_flag, gate_cur, gate_next, n_gate, d_sb_expected, d_tasks, d_islands, \
-                     d_wave_off, d_coeffs, (lf_granule *)ctx->lf_hand, gen, rp)
+                     d_wave_off, d_coeffs, (lf_granule *)ctx->lf_hand, gen, rp, ticket, ticket_next)
   if (!frame->hbd)
     WALK_LF(uint8_t, 0);
   else if (frame->bit_depth == 10)

@@ -43,6 +43,7 @@ extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->lf_err_flag) (void)hipFree(ctx->lf_err_flag);
   if (ctx->lf_hand) (void)hipFree(ctx->lf_hand);
+  if (ctx->lf_ticket) (void)hipFree(ctx->lf_ticket);
   if (ctx->d_taps) (void)hipFree(ctx->d_taps);
   if (ctx->ev_begin) {
     for (int i = 0; i < VP9HIP_TIMER_SLOTS; ++i) {

@@ -26,6 +26,8 @@ struct vp9hip_ctx {
   hipEvent_t *ev_begin, *ev_end;  // VP9HIP_TIMER_SLOTS each, created lazily
   // island counters of the fused walk + filter launch (lf_kernels.hip): two sets in `scratch`, used in turn
   int gate_n, gate_parity;
+  int *lf_ticket;  // two per-launch ticket counters, used in turn (lf_kernels.hip: draw_ticket)
+  int lf_ticket_parity;
 };
 
 #define VP9HIP_FAIL(ctx, code, ...)                          \

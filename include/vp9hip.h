@@ -253,13 +253,15 @@ int vp9hip_loop_filter_frame(vp9hip_ctx *ctx, const vp9hip_lfm *d_lfm, int sb_ro
  * (vp9hip_pack.h fills both).  Every island must fit the LDS window (VP9HIP_ISLAND_FITS; vp9hip_pack.h only builds
  * such islands and sends larger components to the global waves); one that does not is reported by vp9hip_sync.
  *
- * Forward progress by construction: a workgroup only ever waits for workgroups with a LOWER index in the same
- * grid — islands wait for nothing, a filter row waits for the row above and for islands in front of it — and the
- * hardware starts the workgroups of a grid in index order, so whatever else shares the GPU (other contexts, other
- * processes) every wait ends.  h_row_pos (HOST, sb_rows entries, non-decreasing, or NULL) says where the rows sit
- * in the grid: h_row_pos[r] = number of islands in front of the workgroups of filter row r, which must include
- * every island that touches superblock rows <= r + 1 (vp9hip_pack.h sorts the islands accordingly); NULL puts all
- * islands first.  Rows start as early as their islands allow instead of behind the whole walk.
+ * Forward progress by construction: a workgroup's place in the launch's order is a ticket it draws when it starts
+ * running (an atomic counter), so whoever holds a lower ticket is running or done, whatever order the hardware
+ * starts workgroups in; and a workgroup only ever waits for lower tickets — islands wait for nothing, a filter row
+ * waits for the row above and for islands in front of it.  Whatever else shares the GPU (other contexts, other
+ * processes), every wait ends: nobody waits for a workgroup that is not resident.  h_row_pos (HOST, sb_rows
+ * entries, non-decreasing, or NULL) says where the rows sit in that order: h_row_pos[r] = number of islands in front
+ * of the workgroups of filter row r, which must include every island that touches superblock rows <= r + 1
+ * (vp9hip_pack.h sorts the islands accordingly); NULL puts all islands first.  Rows start as early as their islands
+ * allow instead of behind the whole walk.
  *
  * Frames with very large components (key frames: the vp9hip_intra_pred_waves remainder) use the calls in
  * sequence instead.  Ordered after everything enqueued before on the context, and later work is ordered after it.

@@ -13,6 +13,8 @@
 #                                  INTEGRATION.md edits) + CPU bodies   — the stream oracle, 8/10/12 bit
 #   oracle/_ref/vpx/vpxenc_c       the reference's encoder linked with that same decoder
 #                                  (`--test-decode=fatal` pins the oracle; also synthesizes test streams)
+#   oracle/_ref/vpx/ref_svc_encode oracle/ref_svc_encode.c: the reference's encoder API driven for spatial layers
+#                                  (references of another size) and an intra-only frame, same decoder linked in
 #   shim/build/vpxdec_hipA         vpxdec + UNCHANGED frame driver + libvp9hip_shim.so   (PRODUCT, mode A)
 #   shim/build/vpxdec_hip          vpxdec + PATCHED frame driver  + libvp9hip_shim.so   (PRODUCT, mode C)
 #   shim/build/vpxdec_hip_mt       the same + tile-parallel entropy stage (patch_decodeframe.py --mt, E10)
@@ -100,6 +102,10 @@ LINK="-Wl,--gc-sections -lm -lpthread"
 g++ -o "$OUT/vpxdec_cA" $DEC_TOOLS "$OUT/decodeframe_unchanged.o" "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" $LINK
 g++ -o "$OUT/vpxdec_c" $DEC_TOOLS $PATCHED "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" $LINK
 g++ -o "$OUT/vpxenc_c" $ENC_TOOLS $PATCHED "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" $LINK
+
+# ---- spatial-layer / intra-only stream maker: own driver of the reference's encoder API, decoded by the oracle as it goes
+gcc -std=gnu99 -O2 -w $INC -c "$HERE/ref_svc_encode.c" -o "$OUT/ref_svc_encode.o"
+g++ -o "$OUT/ref_svc_encode" "$OUT/ref_svc_encode.o" $PATCHED "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" $LINK
 
 # ---- the product: the same objects against libvp9hip_shim.so ----------------------------------------
 if [ -f "$ROOT/shim/build/libvp9hip_shim.so" ]; then

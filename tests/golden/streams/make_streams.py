@@ -11,7 +11,7 @@ Runs in the development container only (needs oracle/_ref/vpx/{vpxenc_c,vpxdec_c
   3. the reference's vpxdec (CPU wrap_cuda_* bodies) writes the per-frame MD5 list in vpxdec's
      `--md5` format (libvpx/vpxdec.c:285-302, 490-495) — the format of Sony.md5 / netflix.md5.
 Small streams (<= ~200 KB) land in tests/golden/streams/ and are committed; the BASELINE.json-sized
-ones (S-1440, S-2160, S-2176, S-1080-10) land in tests/streams_big/ (git-ignored, travels to the GPU box).
+ones (S-1440, S-2160, S-2176, S-1080-10, S-1440-10, S-1080-8) land in tests/streams_big/ (git-ignored, travels to the GPU box).
 
     python3 tests/golden/streams/make_streams.py [--big] [name ...]
 """
@@ -69,6 +69,20 @@ STREAMS = {
     # quality asks of the entropy stage
     "S-1440-q44": (2560, 1440, 60, 1440, 5, 3, 8, "420", 0.1, 0, ["--cpu-used=2", "--cq-level=44", "--tile-columns=3", "--lag-in-frames=0", "--passes=1"], True),
     "S-1080-10": (1920, 1080, 30, 1080, 7, 4, 10, "420", 0.1, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=2", "--cq-level=28", "--tile-columns=2", "--lag-in-frames=0", "--passes=1"], True),
+    # the headline geometry at 10 bits (Bravia.1440.ivf is almost certainly profile 2 — the reference's kernels only
+    # handle uint16 frames) and the north star's other size at 8 bits
+    "S-1440-10": (2560, 1440, 30, 14410, 5, 3, 10, "420", 0.1, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=3", "--cq-level=26", "--tile-columns=3", "--lag-in-frames=0", "--passes=1"], True),
+    "S-1080-8": (1920, 1080, 60, 10808, 6, -3, 8, "420", 0.1, 0, ["--cpu-used=2", "--cq-level=26", "--tile-columns=2", "--lag-in-frames=0", "--passes=1"], True),
+}
+
+
+# Streams the command-line encoder cannot make (oracle/ref_svc_encode.c drives the reference's encoder API): spatial
+# layers — every superframe holds a half-size (quarter-size) frame and the frames predicted from it through scale
+# factors, so a frame's references have ANOTHER size (vp9_decodeframe.c:1781, 3232-3237) — and an intra-only frame in
+# mid-stream (:3182-3213).  name: (width, height, frames, seed, dx, dy, patch_prob, layers, intra_only_at, kbps, speed)
+SVC_STREAMS = {
+    "s352_svc2": (352, 288, 8, 35202, 3, 2, 0.3, 2, 4, 700, 6),
+    "s704_svc3": (704, 576, 6, 70403, 4, -2, 0.3, 3, 3, 1800, 7),
 }
 
 
@@ -137,8 +151,30 @@ def make(name):
     print(f"{name}: {os.path.getsize(ivf)} bytes, {len(lines)} frames, list md5 {hashlib.md5(''.join(lines).encode()).hexdigest()[:8]}")
 
 
+def make_svc(name):
+    w, h, n, seed, dx, dy, patch, layers, intra_at, kbps, speed = SVC_STREAMS[name]
+    ivf = os.path.join(HERE, name + ".ivf")
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "src.yuv")
+        source(yuv, w, h, n, seed, dx, dy, 8, "420", patch, 0)
+        # (the driver decodes every superframe with the stream oracle and compares the reference buffers with the
+        # encoder's own: its `--test-decode=fatal`)
+        out = run([os.path.join(VPX, "ref_svc_encode"), yuv, str(w), str(h), str(n), ivf, str(layers), str(intra_at), str(kbps), str(speed)])
+        if "decoded identically" not in out:
+            sys.exit(f"{name}: {out[-400:]}")
+    lines = md5_list(os.path.join(VPX, "vpxdec_c"), ivf)
+    if len(lines) != n:
+        sys.exit(f"{name}: {len(lines)} frames shown, {n} expected")
+    with open(os.path.join(HERE, name + ".md5"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print(f"{name}: {os.path.getsize(ivf)} bytes, {len(lines)} shown frames, list md5 {hashlib.md5(''.join(lines).encode()).hexdigest()[:8]}")
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    names = args or [k for k, v in STREAMS.items() if v[-1] == ("--big" in sys.argv)]
+    names = args or ([k for k, v in STREAMS.items() if v[-1] == ("--big" in sys.argv)] + ([] if "--big" in sys.argv else list(SVC_STREAMS)))
     for nm in names:
-        make(nm)
+        if nm in SVC_STREAMS:
+            make_svc(nm)
+        else:
+            make(nm)

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(REFDEC), reason="oracle/_ref/
 
 
 @pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444", "s352_aq1", "s352_aq3", "s352_er", "s352_fp", "s352_ll",
-                                  "s352_12", "s352_tr"])
+                                  "s352_12", "s352_tr", "s352_svc2", "s704_svc3"])
 def test_front_end_parses_what_the_reference_parses(hip, name):
     path = os.path.join(SMALL, name + ".ivf")
     mine = fe_compare.parse_stream(hip, path)
@@ -32,7 +32,7 @@ def test_front_end_same_lists_for_every_thread_count(hip):
     assert len(one) == len(two) and all((a == b).all() for a, b in zip(one, two))
 
 
-@pytest.mark.parametrize("name", ["S-1440", "S-2176", "S-1080-10"])
+@pytest.mark.parametrize("name", ["S-1440", "S-2176", "S-1080-10", "S-1440-10", "S-1080-8"])
 def test_front_end_on_baseline_sized_streams(hip, name):
     path = os.path.join(BIG, name + ".ivf")
     if not os.path.exists(path):

@@ -35,14 +35,14 @@ def check(d, name, *opts):
 
 
 @pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444", "s352_aq1", "s352_aq3", "s352_er", "s352_fp", "s352_ll",
-                                  "s352_12", "s352_tr"])
+                                  "s352_12", "s352_tr", "s352_svc2", "s704_svc3"])
 def test_standalone_decoder_md5(name):
     assert os.path.exists(DEC), "cuda-vp9_amd/vp9hip_dec not built (make -C cuda-vp9_amd)"
     check(SMALL, name)
     check(SMALL, name, "--serial", "--threads=1")
 
 
-@pytest.mark.parametrize("name", ["S-1440", "S-1440-q44", "S-2160", "S-2176", "S-1080-10"])
+@pytest.mark.parametrize("name", ["S-1440", "S-1440-q44", "S-2160", "S-2176", "S-1080-10", "S-1440-10", "S-1080-8"])
 def test_standalone_decoder_md5_baseline_sized(name):
     if not os.path.exists(os.path.join(BIG, name + ".ivf")):
         pytest.skip("tests/streams_big not generated (make_streams.py --big)")

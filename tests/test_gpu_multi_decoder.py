@@ -33,7 +33,7 @@ def _params(hip, W, H, bd):
     return P
 
 
-@pytest.mark.parametrize("W,H,bd,n_dec,rounds", [(2560, 1440, 8, 6, 40), (1280, 720, 10, 4, 60)])
+@pytest.mark.parametrize("W,H,bd,n_dec,rounds", [(2560, 1440, 8, 8, 40), (1280, 720, 10, 4, 60), (640, 368, 8, 12, 100)])
 def test_decoders_in_one_process(hip, W, H, bd, n_dec, rounds):
     import refframe
     import workload

@@ -121,3 +121,40 @@ def test_bench_refuses_more_gpus_than_visible_cleanly():
                        stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 2
     assert "GPU(s) visible" in json.loads(r.stdout.decode().strip().splitlines()[-1])["error"]
+
+
+def test_rank_placement_on_a_described_host():
+    """Per-rank CPU blocks and thread budgets (cuda-vp9_amd/batch.py rank_placement) on a described
+    128-core, two-socket host with eight GPUs — four per NUMA node — and on hosts that say less."""
+    import importlib
+    import __graft_entry__ as g
+    g.load_pkg()
+    batch = importlib.import_module("cuda_vp9_amd.batch")
+    assert batch.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    topo = {"allowed": list(range(128)), "nodes": {0: list(range(64)), 1: list(range(64, 128))},
+            "gpu_numa": [0, 0, 0, 0, 1, 1, 1, 1]}
+    seen = set()
+    for r in range(8):
+        p = batch.rank_placement(r, 8, topo)
+        assert len(p["cpus"]) == 16 and p["cpus"] == list(range(p["cpus"][0], p["cpus"][0] + 16))  # a contiguous block
+        assert set(p["cpus"]) <= set(topo["nodes"][topo["gpu_numa"][r]])                          # on the GPU's node
+        assert not (seen & set(p["cpus"]))                                                        # nobody else's
+        seen |= set(p["cpus"])
+        assert 1 + p["entropy_threads"] + p["pack_threads"] <= 16 and p["entropy_threads"] == 8
+    assert seen == set(range(128))
+    # one GPU of eight on its own: the whole first node
+    assert batch.rank_placement(0, 1, topo)["cpus"] == list(range(64))
+    # a cgroup that allows 32 CPUs across both nodes: blocks come from what is allowed on the GPU's node
+    topo2 = dict(topo, allowed=list(range(0, 16)) + list(range(64, 80)))
+    assert batch.rank_placement(5, 8, topo2)["cpus"] == list(range(68, 72))
+    # no NUMA information: an even split of the allowed CPUs
+    flat = {"allowed": list(range(16)), "nodes": {}, "gpu_numa": []}
+    assert [batch.rank_placement(r, 4, flat)["cpus"] for r in range(4)] == [list(range(4 * r, 4 * r + 4)) for r in range(4)]
+    # more ranks than CPUs: everybody still gets one, budgets of one thread each
+    tiny = {"allowed": [0, 1], "nodes": {}, "gpu_numa": []}
+    p = batch.rank_placement(3, 8, tiny)
+    assert len(p["cpus"]) == 1 and p["entropy_threads"] == 1 and p["pack_threads"] == 1
+    # this host, whatever it is: a non-empty subset of the CPUs the process may use
+    here = batch.host_topology()
+    p = batch.rank_placement(0, 2, here)
+    assert p["cpus"] and set(p["cpus"]) <= set(here["allowed"])
