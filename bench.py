@@ -43,7 +43,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_SOURCES = {"convolve": ["inter_kernels.hip"], "idct_add": ["txfm_kernels.hip", "txfm_device.h"],
-                  "intra": ["intra_kernels.hip", "txfm_device.h"], "loop_filter": ["lf_kernels.hip"]}
+                  "intra": ["intra_kernels.hip", "txfm_device.h"], "loop_filter": ["lf_kernels.hip"],
+                  "walk_lf": ["lf_kernels.hip", "intra_kernels.hip", "txfm_device.h"]}
 
 
 def parse_args():
@@ -141,7 +142,7 @@ def algorithmic_bytes(L, W, H, bd):
     intra = int((bs * bs * bps).sum() + ((3 * bs + 1) * bps).sum() + 16 * len(ia) + ((ia["eob"] > 0) * bs * bs * 4).sum())
     aw, ah = (W + 7) & ~7, (H + 7) & ~7
     lf = int(2 * (aw * ah * 3 // 2) * bps + 160 * L["sb_rows"] * L["sb_cols"])
-    return dict(convolve=conv, idct_add=idct, intra=intra, loop_filter=lf)
+    return dict(convolve=conv, idct_add=idct, intra=intra, loop_filter=lf, walk_lf=intra + lf)
 
 
 def source_hash(files):
@@ -179,11 +180,12 @@ def run_vpxdec(path, ivf, loops=1, md5=False, timeout=600):
     return [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"(\d+) decoded frames/\d+ showed frames in \d+ us \(([\d.]+) fps\)", out)]
 
 
-def run_own_dec(ivf, loops=1, md5=False, timeout=600, device=0):
+def run_own_dec(ivf, loops=1, md5=False, timeout=600, device=0, threads=None):
     """cuda-vp9_amd/vp9hip_dec: the decoder built only from this repository (own bitstream front-end + GPU
     reconstruction).  md5: vpxdec's per-frame lines; else [(frames, fps)] per loop, frames fetched to the host."""
     path = os.path.join(ROOT, "cuda-vp9_amd", "vp9hip_dec")
-    cmd = [path, f"--device={device}"] + (["--md5", "-o", "img-%wx%h-%4.i420"] if md5 else ["--noblit", "--fetch", "--summary", f"--loops={loops}"]) + [ivf]
+    cmd = [path, f"--device={device}"] + ([f"--threads={threads}"] if threads else []) + \
+          (["--md5", "-o", "img-%wx%h-%4.i420"] if md5 else ["--noblit", "--fetch", "--summary", f"--loops={loops}"]) + [ivf]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
     out = r.stdout.decode(errors="replace")
     if r.returncode:
@@ -343,6 +345,14 @@ def main():
     hip = g.load_pkg()
     import cuda_vp9_amd.batch as batch
 
+    # several ranks on one host: a block of CPUs per rank on its GPU's NUMA node and thread budgets from that block
+    # (SURVEY §8e); a single rank keeps the whole host (the CPU baseline's child processes want it)
+    placement = None
+    if world > 1:
+        placement = batch.rank_placement(local_rank, world, batch.host_topology())
+        placement["pinned"] = batch.apply_placement(placement)
+        os.environ["VP9HIP_PACK_THREADS"] = str(placement["pack_threads"])
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -414,18 +424,28 @@ def main():
         dec.run(ALL, (0, 1, 2), 3, thresh=th)
 
     # ---- the timed region: K steps on resident lists ------------------------------------------------
-    for i in range(args.warmup):
+    # K = --steps, raised so that the region lasts at least --min-seconds (a 20-step region is 10 ms of GPU time: too
+    # short to mean anything); decided from the untimed warm-up, the same K on every rank, reported as `steps`
+    tw0 = time.perf_counter()
+    for i in range(max(1, args.warmup)):
         step(i)
+    dec.sync()
+    per_step = (time.perf_counter() - tw0) / max(1, args.warmup)
+    steps = max(args.steps, int(args.min_seconds / max(per_step, 1e-6)) + 1)
+    if dist is not None:
+        k = torch.tensor([steps], dtype=torch.int64, device=dev)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        steps = int(k.item())
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
     dec.sync()  # reports a loop-filter row that gave up waiting, if any
 
     # ---- secondary: pack + PCIe upload + run per step, pipelined through the ring ---------------------
-    n_pipe = max(20, args.steps // 4)
+    n_pipe = max(20, min(steps, 400) // 4)
     for i in range(4):
         dec.begin_frame(P, frames[i % n_frames][0], frames[i % n_frames][2], pinned[i % n_frames], persistent=True)
         dec.run(ALL, (0, 1, 2), 3, thresh=th)
@@ -441,11 +461,13 @@ def main():
     dec.sync()
 
     # ---- per-kernel GPU time: HIP events (the decoder's launch stream) around each phase on its own --
-    PH = (("convolve", hip.PHASE_INTER_PRED), ("idct_add", hip.PHASE_INTER_RESID), ("intra", hip.PHASE_INTRA),
-          ("loop_filter", hip.PHASE_LF))
+    # walk_lf = the island walk and the loop filter as the product runs them: ONE launch (walk_lf_kernel); intra and
+    # loop_filter alone are the two halves run as launches of their own, for reference
+    PH = (("convolve", hip.PHASE_INTER_PRED), ("idct_add", hip.PHASE_INTER_RESID), ("walk_lf", hip.PHASE_INTRA | hip.PHASE_LF),
+          ("intra", hip.PHASE_INTRA), ("loop_filter", hip.PHASE_LF))
     phase_ms = {}
     if not args.no_phase_timers:
-        n_timed = min(args.steps, 100)
+        n_timed = min(steps, 100)
         dec.set_timing(True)
         dec.select_set(sets[0])
         for name, bits in PH:
@@ -458,6 +480,7 @@ def main():
 
     # ---- correctness of what was timed: frame 0 against the reference's own C functions ---------------
     md5_match, cpu_baseline, stream = None, None, None
+    extra_streams = {}
     if rank == 0:
         import refframe
         dec.select_set(sets[0])
@@ -496,6 +519,12 @@ def main():
                     stream["resident_replay"] = real_stream_resident(hip, ivf_big)
                 except Exception as e:  # a secondary figure: never takes the line down
                     stream["resident_replay"] = {"error": str(e)[:300]}
+            # the north star's other size and the headline size at 10 bits, end to end, beside the C path
+            for key, nm in (("stream_1080_8", "S-1080-8"), ("stream_1440_10", "S-1440-10")):
+                try:
+                    extra_streams[key] = stream_pair(nm)
+                except (RuntimeError, subprocess.TimeoutExpired, OSError) as e:
+                    extra_streams[key] = {"error": str(e)[:300]}
 
     # ---- extra leg: several independent decoders in flight on one GPU ---------------------------------
     multi = None
@@ -518,7 +547,7 @@ def main():
                 d.sync()
             barrier()
             barriers = 1
-            n_rounds = max(10, args.steps // 8)
+            n_rounds = max(10, min(steps, 400) // 8)
             import threading
             failures = []
 
@@ -557,7 +586,7 @@ def main():
         fps_mine, frames_mine = 0.0, 0
         if have_own:
             try:  # whatever happens here, every rank reaches the collective below
-                runs = run_own_dec(ivf_big, loops=5, device=local_rank, timeout=300)
+                runs = run_own_dec(ivf_big, loops=5, device=local_rank, timeout=300, threads=placement["entropy_threads"] if placement else None)
                 warm = runs[1:] or runs
                 if warm:
                     fps_mine, frames_mine = sum(f for _, f in warm) / len(warm), warm[0][0]
@@ -570,7 +599,7 @@ def main():
                                    "frames fetched to the host; sum of the ranks' warm-loop rates"}
 
     # stats reduce: total frames (sum) and slowest rank (max) — the only collective in the harness
-    frames_total, _, t_max = batch.reduce_stats(dist, args.steps, 0.0, elapsed, device=dev)
+    frames_total, _, t_max = batch.reduce_stats(dist, steps, 0.0, elapsed, device=dev)
     pipe_total, _, t_pipe_max = batch.reduce_stats(dist, n_pipe, 0.0, t_pipe, device=dev)
 
     if rank == 0:
@@ -583,34 +612,32 @@ def main():
                                  "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5) if gbs else None}
         roofline = None
         if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]["ms_per_frame"])
-            # HBM bytes per launch from rocprofv3 --pmc passes of tools/pmc_collect.sh (FETCH_SIZE x2 as calibrated
-            # on gfx950, WRITE_SIZE); quoted only while the kernel's source is what was profiled
-            traffic, note = None, "no PMC record"
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
-                e = pmc.get(dom)
-                if e and (W, H, bd) == (2560, 1440, 8):
-                    if e.get("source_sha256") == source_hash(KERNEL_SOURCES[dom]):
+            # the launches of a frame as the product runs it: convolve, idct_add, walk_lf (island walk + loop filter)
+            dom = max((k for k in kernels if k in ("convolve", "idct_add", "walk_lf")), key=lambda k: kernels[k]["ms_per_frame"])
+            traffic, note = None, "not measured"
+            if not args.no_pmc and (W, H, bd) == (2560, 1440, 8):
+                key = {"convolve": "inter_reg_kernel", "idct_add": "idct_add_all_kernel", "walk_lf": "walk_lf_kernel"}[dom]
+                try:
+                    traffic, note = measure_traffic(key)
+                except Exception as e:  # noqa: BLE001 — a secondary figure
+                    traffic, note = None, f"PMC child run failed: {str(e)[:200]}"
+            if traffic is None:
+                # fallback: the committed record of tools/pmc_collect.sh, quoted only while the kernel's source is what was profiled
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
+                    e = pmc.get(dom)
+                    if e and (W, H, bd) == (2560, 1440, 8) and e.get("source_sha256") == source_hash(KERNEL_SOURCES[dom]):
                         traffic = int(e["hbm_read_bytes_gfx950_x2"] + e["hbm_write_bytes"])
-                        note = f"profiles/pmc_current.json ({e.get('collected', 'round 2')}), kernel source hash matches"
-                    else:
-                        note = "profiles/pmc_current.json was collected on an older version of this kernel: not quoted"
-                for k, v in kernels.items():
-                    e = pmc.get(k)
-                    if e and e.get("source_sha256") == source_hash(KERNEL_SOURCES[k]):
-                        v["hbm_traffic_bytes_pmc"] = int(e["hbm_read_bytes_gfx950_x2"] + e["hbm_write_bytes"])
-                        if "lds_bank_conflict_frac" in e:
-                            v["lds_bank_conflict_frac_pmc"] = e["lds_bank_conflict_frac"]
-            except (OSError, KeyError, ValueError):
-                pass
+                        note = f"{note}; profiles/pmc_current.json ({e.get('collected', '')}), kernel source hash matches"
+                except (OSError, KeyError, ValueError):
+                    pass
             roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": note}
         blocks0 = frames[0][0]
         out = {
             "metric": "decoded frames/sec (block-reconstruction path: inter+idct+intra+loop filter), 1440p VP9 8-bit",
-            "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4), "higher_is_better": True,
+            "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": steps,
+            "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8" if bd == 8 else "u16", "data": "synthetic",
             "config": {"workload": f"S-{H}: synthetic {W}x{H} {bd}-bit 4:2:0 inter frames with a VP9 partition ({len(blocks0)} "
                                    f"blocks, {len(lists0['inter_tasks'])} inter tasks, {len(lists0['txb'])} coded inter tx blocks, "
@@ -625,7 +652,14 @@ def main():
                                 "host_pack_threads": int(os.environ["VP9HIP_PACK_THREADS"]),
                                 "note": "every step packs the frame on the host and uploads lists + coefficients from "
                                         "page-locked memory (ring of 4 list sets) while the previous frame's kernels run"},
-            "stream": stream, "multi_stream": multi, "stream_per_gpu": streams_per_gpu,
+            # a real bitstream end to end (CPU entropy stage + this path, frames fetched), beside `value` — the GPU-side
+            # rate of the hot path with everything resident
+            "decode_fps": (stream or {}).get("vp9hip_dec_fps"), "decode_fps_vpxdec": (stream or {}).get("vpxdec_hip_mt_fps"),
+            "decode_fps_reference_c": (stream or {}).get("vpxdec_c_fps"),
+            "stream": stream, **extra_streams, "multi_stream": multi,
+            # several decoders in flight on one GPU must never make a filter row give up (tests/test_gpu_multi_decoder.py)
+            "multi_stream_ok": (None if multi is None else "error" not in multi),
+            "stream_per_gpu": streams_per_gpu, "placement": placement,
         }
         print(json.dumps(out))
     dec.close()

@@ -97,8 +97,12 @@ def _apply_tile_layout(cl, tile_layout, keep):
     cl.compact = int(bool(tile_layout.get("compact")))
 
 
+INTER_CLASSES = 14  # VP9HIP_INTER_CLASSES
+INTER_SHAPES = ((4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32), (64, 64))
+
+
 class Packed(ctypes.Structure):
-    _fields_ = [("inter", ctypes.c_void_p), ("n_inter", ctypes.c_int32), ("inter_class_count", ctypes.c_int32 * 6),
+    _fields_ = [("inter", ctypes.c_void_p), ("n_inter", ctypes.c_int32), ("inter_class_count", ctypes.c_int32 * INTER_CLASSES),
                 ("txb", ctypes.c_void_p), ("n_txb", ctypes.c_int32), ("txb_size_count", ctypes.c_int32 * 4),
                 ("intra_island_tasks", ctypes.c_void_p), ("n_intra_island_tasks", ctypes.c_int32),
                 ("islands", ctypes.c_void_p), ("n_islands", ctypes.c_int32), ("n_islands_lds", ctypes.c_int32),
@@ -566,7 +570,7 @@ class Context:
 
     def inter_pred_batch(self, d_tasks, class_count, refs, dst):
         arr = (Frame * len(refs))(*[r.desc for r in refs])
-        cc = (ctypes.c_int32 * 6)(*[int(v) for v in class_count])
+        cc = (ctypes.c_int32 * INTER_CLASSES)(*[int(v) for v in class_count])
         self.check(lib().vp9hip_inter_pred_batch(self.handle, ctypes.c_void_p(d_tasks.ptr), cc,
                                                  arr, len(refs), ctypes.byref(dst.desc)))
 
@@ -610,17 +614,15 @@ class Context:
 
 
 def sort_inter_tasks(tasks, hbd):
-    """Group inter tasks into the six classes vp9hip_inter_pred_batch takes."""
+    """Group inter tasks into the classes vp9hip_inter_pred_batch takes (vp9hip_inter_class, include/vp9hip.h)."""
     compound = (tasks["flags"] & 1).astype(bool)
     unscaled = (tasks["step_x"][:, 0] == 16) & (tasks["step_y"][:, 0] == 16) & \
                (~compound | ((tasks["step_x"][:, 1] == 16) & (tasks["step_y"][:, 1] == 16)))  # the second reference only counts when used
-    cls = np.full(len(tasks), 5, np.int32)
-    # fast classes (8-bit and 16-bit samples) cover the VP9 block shapes: width W with height <= HMAX(W),
-    # a multiple of 4
-    for k, (w, hmax) in enumerate(((4, 8), (8, 16), (16, 32), (32, 64), (64, 64))):
-        cls[unscaled & (tasks["w"] == w) & (tasks["h"] <= hmax) & (tasks["h"] % 4 == 0)] = k
+    cls = np.full(len(tasks), INTER_CLASSES - 1, np.int32)
+    for k, (w, h) in enumerate(INTER_SHAPES):
+        cls[unscaled & (tasks["w"] == w) & (tasks["h"] == h)] = k
     order = np.argsort(cls, kind="stable")
-    return tasks[order], [int((cls == k).sum()) for k in range(6)]
+    return tasks[order], [int((cls == k).sum()) for k in range(INTER_CLASSES)]
 
 
 def sort_txb_by_size(blocks):

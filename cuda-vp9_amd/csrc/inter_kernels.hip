@@ -350,11 +350,16 @@ struct RefTable {
   RefPlane d[VP9HIP_MAX_REFS][3];
 };
 
-template <int W>
+// A task of shape W x H: W / 4 lanes per strip, strips of SH rows (4 for the ..x4 shapes, else 8), H / SH strips —
+// exactly the lanes its shape needs (with one allocation per WIDTH, sized for the tallest shape, 40 % of the lanes of a
+// frame with a VP9 partition had no work, and the 4x4 tasks — 70 % of all — filtered 15 window rows for 4).
+template <int W, int H>
 struct RegCfg {
-  static constexpr int L = W / 4;                                                 // lanes per strip
-  static constexpr int HMAX = W == 4 ? 8 : (W == 8 ? 16 : (W == 16 ? 32 : 64));
-  static constexpr int SPT = HMAX / 8;                                            // strips per task
+  static constexpr int L = W / 4;            // lanes per strip
+  static constexpr int SH = H == 4 ? 4 : 8;  // rows per strip
+  static constexpr int SPT = H / SH;         // strips per task
+  static constexpr int NR = SH + 7;          // window rows of a strip
+  static constexpr int NG = (NR + 4) / 4;    // groups of four window rows (the last one padded)
 };
 constexpr int REG_THREADS = 256;
 #ifndef REG_WAVES
@@ -422,29 +427,29 @@ __device__ __forceinline__ void transpose4(unsigned a, unsigned b, unsigned c, u
 __device__ const unsigned kEdgeSel[7] = { 0x00000000u, 0x01000000u, 0x02010000u, 0x03020100u,
                                           0x03030201u, 0x03030302u, 0x03030303u };
 
-template <int W>
+template <int W, int H>
 __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *__restrict__ tasks, int n_tasks,
                                                const RefTable &refs, const FrameDev &dstf,
                                                const unsigned *__restrict__ taps) {
-  typedef RegCfg<W> C;
+  typedef RegCfg<W, H> C;
+  constexpr int SH = C::SH, NR = C::NR, NG = C::NG;
   const int gl = wg * REG_THREADS + threadIdx.x;
   const int strip = gl / C::L, j = gl % C::L;
   const int ti = strip / C::SPT, sub = strip % C::SPT;
-  bool active = ti < n_tasks;
+  const bool active = ti < n_tasks;
   vp9hip_inter_task t;
   if (active) t = tasks[ti];
-  active = active && sub * 8 < t.h;
   const int plane = active ? t.plane : 0;
   const int filt = active ? (t.flags >> 1) & 7 : 0;
   const int nref = active ? ((t.flags & 1) ? 2 : 1) : 0;
-  const int dx = active ? t.dst_x + 4 * j : 0, dy = active ? t.dst_y + sub * 8 : 0;
+  const int dx = active ? t.dst_x + 4 * j : 0, dy = active ? t.dst_y + sub * SH : 0;
   const int dstride = dstf.stride[plane];
   // awidth is a multiple of 8 and dx of 4: a lane's four columns are visible together or not at all
-  const int vis_h = (active && dx < dstf.awidth[plane]) ? min(min(8, (int)t.h - sub * 8), dstf.aheight[plane] - dy) : 0;
+  const int vis_h = (active && dx < dstf.awidth[plane]) ? min(SH, dstf.aheight[plane] - dy) : 0;
   unsigned char *dst = (unsigned char *)dstf.plane[plane] + (size_t)dy * dstride + dx;
-  unsigned k[8];  // first prediction of a compound strip
+  unsigned k[SH];  // first prediction of a compound strip
 #pragma unroll
-  for (int y = 0; y < 8; ++y) k[y] = 0;
+  for (int y = 0; y < SH; ++y) k[y] = 0;
 
 #pragma unroll 1
   for (int r = 0; r < 2; ++r) {
@@ -452,15 +457,15 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
     if (__builtin_amdgcn_ballot_w64(on) == 0) break;
     if (on) {
       const int px = r ? t.pos_x[1] : t.pos_x[0], py = r ? t.pos_y[1] : t.pos_y[0];
-      const int x0 = (px >> 4) + 4 * j, y0 = (py >> 4) + sub * 8;
+      const int x0 = (px >> 4) + 4 * j, y0 = (py >> 4) + sub * SH;
       const int subx = px & 15, suby = py & 15;
       const RefPlane rp = refs.d[r ? t.ref[1] : t.ref[0]][plane];
       const int xs = x0 - 4;
-      unsigned d[15][3];
+      unsigned d[NR][3];
       const bool col_ok = xs >= 0 && xs + 12 <= rp.w;
       if (__builtin_amdgcn_ballot_w64(!col_ok) == 0) {
 #pragma unroll
-        for (int i = 0; i < 15; ++i) {
+        for (int i = 0; i < NR; ++i) {
           const int sy = min(max(y0 - 3 + i, 0), rp.h - 1);
           __builtin_memcpy(d[i], rp.p + (size_t)sy * rp.stride + xs, 12);
         }
@@ -474,7 +479,7 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
           sel[q] = kEdgeSel[min(max(xq - xc[q], -3), 3) + 3];
         }
 #pragma unroll
-        for (int i = 0; i < 15; ++i) {
+        for (int i = 0; i < NR; ++i) {
           const int sy = min(max(y0 - 3 + i, 0), rp.h - 1);
           const unsigned char *rowp = rp.p + (size_t)sy * rp.stride;
 #pragma unroll
@@ -486,28 +491,29 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
         }
       }
       // rows
-      unsigned hr[16];
+      unsigned hr[4 * NG];
       {
         const unsigned flo = taps[(filt * 16 + subx) * 2], fhi = taps[(filt * 16 + subx) * 2 + 1];
 #pragma unroll
-        for (int i = 0; i < 15; ++i) {
+        for (int i = 0; i < NR; ++i) {
           const unsigned f = filt4<1>(d[i][0] ^ 0x80808080u, d[i][1] ^ 0x80808080u, d[i][2] ^ 0x80808080u, flo, fhi);
           hr[i] = subx == 0 ? d[i][1] : f;
         }
-        hr[15] = 0;
+#pragma unroll
+        for (int i = NR; i < 4 * NG; ++i) hr[i] = 0;
       }
       // columns
-      unsigned col[4][4];
+      unsigned col[4][NG];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < NG; ++g) {
         transpose4(hr[4 * g], hr[4 * g + 1], hr[4 * g + 2], hr[4 * g + 3], col[0][g], col[1][g], col[2][g], col[3][g]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) col[c][g] ^= 0x80808080u;
       }
       const unsigned flo = taps[(filt * 16 + suby) * 2], fhi = taps[(filt * 16 + suby) * 2 + 1];
-      unsigned out[8];
+      unsigned out[SH];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < SH / 4; ++m) {
         unsigned v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = filt4<0>(col[c][m], col[c][m + 1], col[c][m + 2], flo, fhi);
@@ -515,7 +521,7 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
         transpose4(v[0], v[1], v[2], v[3], out[4 * m], out[4 * m + 1], out[4 * m + 2], out[4 * m + 3]);
       }
 #pragma unroll
-      for (int y = 0; y < 8; ++y) {
+      for (int y = 0; y < SH; ++y) {
         const unsigned o = suby == 0 ? hr[y + 3] : out[y];
         // second reference of a compound strip: per byte (a + b + 1) >> 1 (vpx_convolve_avg_c)
         const unsigned res = r == 1 ? (k[y] | o) - (((k[y] ^ o) >> 1) & 0x7f7f7f7fu) : o;
@@ -527,31 +533,44 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
   }
 }
 
+// The thirteen shapes of vp9hip_inter_class in one launch: workgroups [wg_start[k], wg_start[k+1]) serve shape k.
+constexpr int REG_SHAPES = VP9HIP_INTER_CLASSES - 1;
+struct RegPlan {
+  int wg_start[REG_SHAPES + 1];
+  int task_start[REG_SHAPES];
+  int task_count[REG_SHAPES];
+};
+
 __global__ __launch_bounds__(REG_THREADS) __attribute__((amdgpu_waves_per_eu(REG_WAVES, REG_WAVES))) void inter_reg_kernel(const vp9hip_inter_task *__restrict__ tasks,
-                                                                FastPlan plan, RefTable refs, FrameDev dstf,
+                                                                RegPlan plan, RefTable refs, FrameDev dstf,
                                                                 const unsigned *__restrict__ taps) {
   const int b = blockIdx.x;
-  if (b < plan.wg_start[1])
-    inter_reg_body<4>(xcd_order(b, plan.wg_start[0], plan.wg_start[1]), tasks + plan.task_start[0], plan.task_count[0],
-                      refs, dstf, taps);
-  else if (b < plan.wg_start[2])
-    inter_reg_body<8>(xcd_order(b, plan.wg_start[1], plan.wg_start[2]), tasks + plan.task_start[1], plan.task_count[1],
-                      refs, dstf, taps);
-  else if (b < plan.wg_start[3])
-    inter_reg_body<16>(xcd_order(b, plan.wg_start[2], plan.wg_start[3]), tasks + plan.task_start[2],
-                       plan.task_count[2], refs, dstf, taps);
-  else if (b < plan.wg_start[4])
-    inter_reg_body<32>(xcd_order(b, plan.wg_start[3], plan.wg_start[4]), tasks + plan.task_start[3],
-                       plan.task_count[3], refs, dstf, taps);
-  else
-    inter_reg_body<64>(xcd_order(b, plan.wg_start[4], plan.wg_start[5]), tasks + plan.task_start[4],
-                       plan.task_count[4], refs, dstf, taps);
+  int k = 0;
+  while (k < REG_SHAPES - 1 && b >= plan.wg_start[k + 1]) ++k;
+  const int wg = xcd_order(b, plan.wg_start[k], plan.wg_start[k + 1]);
+  const vp9hip_inter_task *tk = tasks + plan.task_start[k];
+  const int n = plan.task_count[k];
+  switch (k) {
+    case 0: inter_reg_body<4, 4>(wg, tk, n, refs, dstf, taps); break;
+    case 1: inter_reg_body<4, 8>(wg, tk, n, refs, dstf, taps); break;
+    case 2: inter_reg_body<8, 4>(wg, tk, n, refs, dstf, taps); break;
+    case 3: inter_reg_body<8, 8>(wg, tk, n, refs, dstf, taps); break;
+    case 4: inter_reg_body<8, 16>(wg, tk, n, refs, dstf, taps); break;
+    case 5: inter_reg_body<16, 8>(wg, tk, n, refs, dstf, taps); break;
+    case 6: inter_reg_body<16, 16>(wg, tk, n, refs, dstf, taps); break;
+    case 7: inter_reg_body<16, 32>(wg, tk, n, refs, dstf, taps); break;
+    case 8: inter_reg_body<32, 16>(wg, tk, n, refs, dstf, taps); break;
+    case 9: inter_reg_body<32, 32>(wg, tk, n, refs, dstf, taps); break;
+    case 10: inter_reg_body<32, 64>(wg, tk, n, refs, dstf, taps); break;
+    case 11: inter_reg_body<64, 32>(wg, tk, n, refs, dstf, taps); break;
+    default: inter_reg_body<64, 64>(wg, tk, n, refs, dstf, taps); break;
+  }
 }
 
-template <int W>
+template <int W, int H>
 int reg_wgs(int n) {
-  constexpr int per_wg = REG_THREADS / RegCfg<W>::L;  // strips per workgroup
-  return (int)(((long long)n * RegCfg<W>::SPT + per_wg - 1) / per_wg);
+  constexpr int per_wg = REG_THREADS / RegCfg<W, H>::L;  // strips per workgroup
+  return (int)(((long long)n * RegCfg<W, H>::SPT + per_wg - 1) / per_wg);
 }
 
 __global__ __launch_bounds__(FAST_THREADS) void inter_fast16_kernel(const vp9hip_inter_task *__restrict__ tasks,
@@ -600,7 +619,7 @@ int upload_taps(vp9hip_ctx *ctx) {
 }  // namespace
 
 extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task *d_tasks,
-                                       const int32_t class_count[6], const vp9hip_frame *refs, int n_refs,
+                                       const int32_t class_count[VP9HIP_INTER_CLASSES], const vp9hip_frame *refs, int n_refs,
                                        const vp9hip_frame *dst) {
   if (!ctx) return VP9HIP_EINVAL;
   VP9HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the caller's thread may be on another device
@@ -614,9 +633,9 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
     rs.f[i] = to_dev(&refs[i]);
   }
   int fast_total = 0;
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < VP9HIP_INTER_CLASSES; ++i) {
     if (class_count[i] < 0) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_inter_pred_batch: negative class count");
-    if (i < 5) fast_total += class_count[i];
+    if (i < VP9HIP_INTER_CLASSES - 1) fast_total += class_count[i];
   }
   const FrameDev d = to_dev(dst);
   int rc;
@@ -631,40 +650,54 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
   if (fast_total && !dst->hbd && tiny_ref) {
     hipLaunchKernelGGL(inter_pred_kernel<uint8_t>, dim3(fast_total), dim3(64), 0, ctx->stream, d_tasks, fast_total, rs, d);
     VP9HIP_CHECK(ctx, hipGetLastError());
-  } else if (fast_total) {
+  } else if (fast_total && dst->hbd) {
+    // 16-bit samples: the LDS-tiled kernel works per WIDTH (the shapes of one width are neighbours in the list)
+    const int by_w[5] = { class_count[0] + class_count[1], class_count[2] + class_count[3] + class_count[4],
+                          class_count[5] + class_count[6] + class_count[7], class_count[8] + class_count[9] + class_count[10],
+                          class_count[11] + class_count[12] };
     FastPlan plan;
-    const int wgs16[5] = { fast_wgs<4>(class_count[0]), fast_wgs<8>(class_count[1]), fast_wgs<16>(class_count[2]),
-                           fast_wgs<32>(class_count[3]), fast_wgs<64>(class_count[4]) };
-    const int wgs8[5] = { reg_wgs<4>(class_count[0]), reg_wgs<8>(class_count[1]), reg_wgs<16>(class_count[2]),
-                          reg_wgs<32>(class_count[3]), reg_wgs<64>(class_count[4]) };
-    const int *wgs = dst->hbd ? wgs16 : wgs8;
+    const int wgs16[5] = { fast_wgs<4>(by_w[0]), fast_wgs<8>(by_w[1]), fast_wgs<16>(by_w[2]), fast_wgs<32>(by_w[3]), fast_wgs<64>(by_w[4]) };
     int acc_w = 0, acc_t = 0;
     for (int k = 0; k < 5; ++k) {
       plan.wg_start[k] = acc_w;
       plan.task_start[k] = acc_t;
-      plan.task_count[k] = class_count[k];
-      acc_w += wgs[k];
-      acc_t += class_count[k];
+      plan.task_count[k] = by_w[k];
+      acc_w += wgs16[k];
+      acc_t += by_w[k];
     }
     plan.wg_start[5] = acc_w;
-    if (dst->hbd) {
-      hipLaunchKernelGGL(inter_fast16_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d);
-    } else {
-      RefTable rt;
-      memset(&rt, 0, sizeof(rt));
-      for (int i = 0; i < n_refs; ++i)
-        for (int pl = 0; pl < 3; ++pl) {
-          rt.d[i][pl].p = (const unsigned char *)refs[i].plane[pl];
-          rt.d[i][pl].stride = refs[i].stride[pl];
-          rt.d[i][pl].w = refs[i].width[pl];
-          rt.d[i][pl].h = refs[i].height[pl];
-        }
-      hipLaunchKernelGGL(inter_reg_kernel, dim3(acc_w), dim3(REG_THREADS), 0, ctx->stream, d_tasks, plan, rt, d,
-                         (const unsigned *)ctx->d_taps);
+    hipLaunchKernelGGL(inter_fast16_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d);
+    VP9HIP_CHECK(ctx, hipGetLastError());
+  } else if (fast_total) {
+    RegPlan plan;
+    const int wgs8[REG_SHAPES] = { reg_wgs<4, 4>(class_count[0]),    reg_wgs<4, 8>(class_count[1]),   reg_wgs<8, 4>(class_count[2]),
+                                   reg_wgs<8, 8>(class_count[3]),    reg_wgs<8, 16>(class_count[4]),  reg_wgs<16, 8>(class_count[5]),
+                                   reg_wgs<16, 16>(class_count[6]),  reg_wgs<16, 32>(class_count[7]), reg_wgs<32, 16>(class_count[8]),
+                                   reg_wgs<32, 32>(class_count[9]),  reg_wgs<32, 64>(class_count[10]), reg_wgs<64, 32>(class_count[11]),
+                                   reg_wgs<64, 64>(class_count[12]) };
+    int acc_w = 0, acc_t = 0;
+    for (int k = 0; k < REG_SHAPES; ++k) {
+      plan.wg_start[k] = acc_w;
+      plan.task_start[k] = acc_t;
+      plan.task_count[k] = class_count[k];
+      acc_w += wgs8[k];
+      acc_t += class_count[k];
     }
+    plan.wg_start[REG_SHAPES] = acc_w;
+    RefTable rt;
+    memset(&rt, 0, sizeof(rt));
+    for (int i = 0; i < n_refs; ++i)
+      for (int pl = 0; pl < 3; ++pl) {
+        rt.d[i][pl].p = (const unsigned char *)refs[i].plane[pl];
+        rt.d[i][pl].stride = refs[i].stride[pl];
+        rt.d[i][pl].w = refs[i].width[pl];
+        rt.d[i][pl].h = refs[i].height[pl];
+      }
+    hipLaunchKernelGGL(inter_reg_kernel, dim3(acc_w), dim3(REG_THREADS), 0, ctx->stream, d_tasks, plan, rt, d,
+                       (const unsigned *)ctx->d_taps);
     VP9HIP_CHECK(ctx, hipGetLastError());
   }
-  const int n_gen = class_count[5];
+  const int n_gen = class_count[VP9HIP_INTER_CLASSES - 1];
   if (n_gen > 0) {
     if (dst->hbd)
       hipLaunchKernelGGL(inter_pred_kernel<uint16_t>, dim3(n_gen), dim3(64), 0, ctx->stream, p, n_gen, rs, d);

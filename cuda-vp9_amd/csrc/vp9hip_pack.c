@@ -18,6 +18,18 @@ static const uint8_t kH4[13] = { 1, 2, 1, 2, 4, 2, 4, 8, 4, 8, 16, 8, 16 };
 /* intra_mode_to_tx_type_lookup (vp9/common/vp9_reconintra.c:24-35): DC V H D45 D135 D117 D153 D207 D63 TM */
 static const uint8_t kModeToTxType[10] = { 0, 1, 2, 0, 3, 1, 2, 2, 1, 3 };
 
+/* the classes of vp9hip_inter_pred_batch (include/vp9hip.h) */
+int vp9hip_inter_class(int w, int h, int unscaled) {
+  if (unscaled) {
+    if (w == 4 && (h == 4 || h == 8)) return h == 4 ? 0 : 1;
+    if (w == 8 && (h == 4 || h == 8 || h == 16)) return h == 4 ? 2 : (h == 8 ? 3 : 4);
+    if (w == 16 && (h == 8 || h == 16 || h == 32)) return h == 8 ? 5 : (h == 16 ? 6 : 7);
+    if (w == 32 && (h == 16 || h == 32 || h == 64)) return h == 16 ? 8 : (h == 32 ? 9 : 10);
+    if (w == 64 && (h == 32 || h == 64)) return h == 32 ? 11 : 12;
+  }
+  return VP9HIP_INTER_CLASSES - 1;
+}
+
 #define MAX_ISLAND_TASKS 4096
 #define ISLAND_GROUP_TASKS 192
 
@@ -566,10 +578,10 @@ typedef struct pk_job_s {
   int64_t run_off[PK_MAX_THREADS][3];
   int64_t coeff_base[3], coeff_total;
   /* per-range results of pass 1 */
-  int32_t n_txb[PK_MAX_THREADS], hist_inter[PK_MAX_THREADS][6], hist_txb[PK_MAX_THREADS][4];
+  int32_t n_txb[PK_MAX_THREADS], hist_inter[PK_MAX_THREADS][VP9HIP_INTER_CLASSES], hist_txb[PK_MAX_THREADS][4];
   uint32_t refs_used[PK_MAX_THREADS];
   /* sorted positions handed to the scatter */
-  int32_t pos_inter[PK_MAX_THREADS][6], pos_txb[PK_MAX_THREADS][4];
+  int32_t pos_inter[PK_MAX_THREADS][VP9HIP_INTER_CLASSES], pos_txb[PK_MAX_THREADS][4];
   /* arrays */
   vp9hip_inter_task *it, *it_sorted;
   vp9hip_txb *tb, *tb_sorted;
@@ -667,7 +679,7 @@ static void pk_pass1(void *argp, int tid) {
   int ni = j->inter_off[tid], nt = j->txb_off[tid], na = j->intra_off[tid];
   int64_t run[3] = { j->run_off[tid][0], j->run_off[tid][1], j->run_off[tid][2] };
   uint32_t refs_used = 0;
-  int32_t hist_inter[6] = { 0, 0, 0, 0, 0, 0 }, hist_txb[4] = { 0, 0, 0, 0 }; /* local: no shared cache lines */
+  int32_t hist_inter[VP9HIP_INTER_CLASSES] = { 0 }, hist_txb[4] = { 0, 0, 0, 0 }; /* local: no shared cache lines */
   if (raw && j->range[tid] < j->range[tid + 1]) {
     /* the range is a run of whole superblocks in decode order: clear exactly the records it owns */
     int prev = -1;
@@ -752,8 +764,7 @@ static void pk_pass1(void *argp, int tid) {
               t->step_x[1] = t->step_y[1] = 16;
             }
             {
-              int cls = 5;
-              if (!any_scaled) cls = t->w == 4 ? 0 : t->w == 8 ? 1 : t->w == 16 ? 2 : t->w == 32 ? 3 : 4;
+              const int cls = vp9hip_inter_class(t->w, t->h, !any_scaled);
               key[ni] = cls;
               ++hist_inter[cls];
             }
@@ -863,7 +874,7 @@ static void pk_pass1(void *argp, int tid) {
 static void pk_scatter(void *argp, int tid) {
   pk_job *j = (pk_job *)argp;
   if (tid >= j->threads) return;
-  int32_t pos[6];
+  int32_t pos[VP9HIP_INTER_CLASSES];
   memcpy(pos, j->pos_inter[tid], sizeof(pos));
   for (int i = j->inter_off[tid], e = i + j->n_inter[tid]; i < e; ++i) j->it_sorted[pos[j->key[i]]++] = j->it[i];
   memcpy(pos, j->pos_txb[tid], sizeof(int32_t) * 4);
@@ -1023,7 +1034,7 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
   uint32_t refs_used = 0;
   {
     int32_t run_i = 0, run_t = 0;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < VP9HIP_INTER_CLASSES; ++k) {
       out->inter_class_count[k] = 0;
       for (int t = 0; t < threads; ++t) {
         j->pos_inter[t][k] = run_i;

@@ -140,14 +140,19 @@ typedef struct vp9hip_inter_task {
 } vp9hip_inter_task; /* 32 bytes */
 
 #define VP9HIP_MAX_REFS 8
-/* d_tasks (DEVICE) is grouped into six classes, class_count[] (HOST) giving their sizes in order:
- *   0..4  unscaled (step 16) tasks of width 4, 8, 16, 32, 64 and height a multiple of 4 not above
- *         8, 16, 32, 64, 64 respectively (the VP9 block shapes)  -> LDS fast kernels (dot4 on 8-bit
- *         samples, dot2 on 16-bit samples)
- *   5     everything else (scaled references, other shapes)      -> generic kernel
+/* d_tasks (DEVICE) is grouped into VP9HIP_INTER_CLASSES classes, class_count[] (HOST) giving their sizes in order:
+ *   0..12  unscaled (step 16) tasks of exactly one of VP9's block shapes, in this order (vp9hip_inter_class):
+ *          4x4 4x8 | 8x4 8x8 8x16 | 16x8 16x16 16x32 | 32x16 32x32 32x64 | 64x32 64x64   (width x height)
+ *          -> the fast kernels: every lane owns four output columns of a strip of 4 (the two ..x4 shapes) or 8 rows
+ *          and a task takes exactly the lanes its shape needs (8-bit samples: registers only, dot4; 16-bit: LDS
+ *          tiles, dot2)
+ *   13     everything else (scaled references, other shapes)      -> generic kernel
  * Tasks must not overlap in the destination.  Asynchronous on the context's stream. */
-int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task *d_tasks, const int32_t class_count[6],
-                            const vp9hip_frame *refs, int n_refs, const vp9hip_frame *dst);
+#define VP9HIP_INTER_CLASSES 14
+int vp9hip_inter_class(int w, int h, int unscaled); /* the class of a task: host code, no GPU */
+int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task *d_tasks,
+                            const int32_t class_count[VP9HIP_INTER_CLASSES], const vp9hip_frame *refs, int n_refs,
+                            const vp9hip_frame *dst);
 
 /* ------------------------------------------------------------------------------------------
  * (a8–a10) intra prediction, dependency-wave ordered.  One record per transform block

@@ -124,9 +124,9 @@ int vp9hip_coeff_rows(int eob, int tx_type, int tx_size);
 int vp9hip_coeff_extent(int eob, int tx_type, int tx_size);
 
 typedef struct vp9hip_packed {
-  /* inter prediction, sorted into the six classes of vp9hip_inter_pred_batch */
+  /* inter prediction, sorted into the classes of vp9hip_inter_pred_batch */
   const vp9hip_inter_task *inter;
-  int32_t n_inter, inter_class_count[6];
+  int32_t n_inter, inter_class_count[VP9HIP_INTER_CLASSES];
   /* residual of inter blocks, sorted by transform size (vp9hip_idct_add_batch) */
   const vp9hip_txb *txb;
   int32_t n_txb, txb_size_count[4];

@@ -9,6 +9,8 @@ import ctypes
 import numpy as np
 import __graft_entry__ as g
 hip = g.load_pkg()
+if os.environ.get("VP9HIP_TOOLS_LIB"):  # A/B of library builds (tools only)
+    hip.LIB_PATH = os.environ["VP9HIP_TOOLS_LIB"]
 import blockgen
 import workload
 W, H = 2560, 1440

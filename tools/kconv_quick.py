@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_pkg()
+if os.environ.get("VP9HIP_TOOLS_LIB"):  # A/B of library builds (tools only)
+    pkg.LIB_PATH = os.environ["VP9HIP_TOOLS_LIB"]
 ctx = pkg.Context(0)
 rng = np.random.default_rng(7)
 out = []

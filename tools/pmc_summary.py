@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the kernel sources a family's record belongs to (bench.py quotes a record only while this hash matches)
 SOURCES = {"convolve": ["inter_kernels.hip"], "idct_add": ["txfm_kernels.hip", "txfm_device.h"],
            "intra": ["intra_kernels.hip", "txfm_device.h"], "intra_residual": ["intra_kernels.hip", "txfm_device.h"],
-           "loop_filter": ["lf_kernels.hip"]}
+           "loop_filter": ["lf_kernels.hip"], "walk_lf": ["lf_kernels.hip", "intra_kernels.hip", "txfm_device.h"]}
 
 
 def source_hash(files):
@@ -28,7 +28,7 @@ def source_hash(files):
     return h.hexdigest()[:16]
 
 FAMILY = (("inter_fast_kernel", "convolve"), ("inter_fast16_kernel", "convolve"), ("inter_reg_kernel", "convolve"), ("inter_pred_kernel", "convolve_generic"), ("idct_add", "idct_add"),
-          ("intra_island_kernel", "intra"), ("intra_residual_kernel", "intra_residual"), ("intra_wave_kernel", "intra_waves"), ("lf_rows", "loop_filter"),
+          ("walk_lf_kernel", "walk_lf"), ("intra_island_kernel", "intra"), ("intra_residual_kernel", "intra_residual"), ("intra_wave_kernel", "intra_waves"), ("lf_rows", "loop_filter"),
           ("lf_diag", "loop_filter_diag"), ("residual_", "residual"))
 
 

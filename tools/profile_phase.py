@@ -2,9 +2,9 @@
 """Run the phases of the bench frame through the product path (C packer + vp9hip_decoder_run) for rocprofv3
 kernel-trace / --pmc runs.
     rocprofv3 --pmc FETCH_SIZE -- python3 tools/profile_phase.py --separate --steps 6
---separate: every phase in its own vp9hip_decoder_run (rocprofv3 --pmc executes one kernel at a time, and the
-overlapped pair — the filter polls counters the island walk raises — needs both resident); default: whole
-frames, island walk || loop filter as in bench.py."""
+--separate: every launch in its own vp9hip_decoder_run, synchronised (rocprofv3 --pmc executes one kernel at a time):
+convolve, transforms, the fused island walk + loop filter (walk_lf_kernel: one launch, fine under --pmc), then the two
+halves as launches of their own; default: whole frames as in bench.py."""
 import argparse
 import ctypes
 import os
@@ -37,7 +37,7 @@ dec.run(ALL, (0, 1, 2), 3, thresh=th)
 dec.sync()
 for i in range(args.steps):
     if args.separate:
-        for bits in (hip.PHASE_INTER_PRED, hip.PHASE_INTER_RESID, hip.PHASE_INTRA, hip.PHASE_LF):
+        for bits in (hip.PHASE_INTER_PRED, hip.PHASE_INTER_RESID, hip.PHASE_INTRA | hip.PHASE_LF, hip.PHASE_INTRA, hip.PHASE_LF):
             dec.run(bits, (0, 1, 2), 3, thresh=th)
             dec.sync()
     else:
