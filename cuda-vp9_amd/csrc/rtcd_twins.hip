@@ -147,7 +147,7 @@ void twin_convolve(int mode, const void *src, ptrdiff_t sstride, void *dst, ptrd
        *d_o = vp9hip_malloc(c, bstride * 64 * bps), *d_t = vp9hip_malloc(c, sizeof(vp9hip_inter_task));
   vp9hip_inter_task t;
   vp9hip_frame refs[2], df;
-  int32_t counts[6] = { 0, 0, 0, 0, 0, 0 };
+  int32_t counts[VP9HIP_INTER_CLASSES] = { 0 };
   if (!hw || !hb || !d_w || !d_d || !d_o || !d_t) {
     snprintf(g_rtcd_err, sizeof(g_rtcd_err), "convolve twin: out of memory");
     goto done;
@@ -182,9 +182,9 @@ void twin_convolve(int mode, const void *src, ptrdiff_t sstride, void *dst, ptrd
   refs[1] = one_plane(d_o, w, h, bstride, bd, hbd);
   df = one_plane(d_d, w, h, bstride, bd, hbd);
   {
-    const bool vp9_shape = (w == 4 && h <= 8) || (w == 8 && h <= 16) || (w == 16 && h <= 32) || (w == 32) || (w == 64);
-    const bool fast = !hbd && xs == 16 && ys == 16 && vp9_shape && (h % 4 == 0);
-    const int cls = !fast ? 5 : (w == 4 ? 0 : w == 8 ? 1 : w == 16 ? 2 : w == 32 ? 3 : 4);
+    // (16-bit samples and scaled steps take the generic kernel, like the reference's dispatch table does not
+    // distinguish them either: vp9_scale.c:79-170)
+    const int cls = vp9hip_inter_class(w, h, !hbd && xs == 16 && ys == 16);
     counts[cls] = 1;
   }
   TW_CHECK(vp9hip_memcpy_h2d(c, d_w, hw, (size_t)wstride * wh * bps));

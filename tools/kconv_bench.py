@@ -33,7 +33,7 @@ for (W, H) in ((2560, 1440), (3840, 2160), (3840, 2160 * 8)):
                     t = np.zeros(n, pkg.INTER_DTYPE)
                     t["dst_x"], t["dst_y"] = xs.ravel(), ys.ravel()
                     t["w"] = b
-                    t["h"] = np.minimum(b, ph - ys.ravel())
+                    t["h"] = b  # nominal block height (a VP9 shape); the kernels clip at the frame's edge
                     t["plane"] = p
                     t["flags"] = (rng.integers(0, 3, n) << 1) | compound
                     for r in range(2):
