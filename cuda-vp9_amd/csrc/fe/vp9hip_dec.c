@@ -235,6 +235,7 @@ typedef struct {
   pthread_mutex_t mu;
   pthread_cond_t cv;
   vp9hip_fe_frame frame;
+  int frame_last; /* the last frame of its packet: the only one of a superframe a decoder puts out */
   int has, quit;
 } Gpu;
 
@@ -252,9 +253,14 @@ static int gpu_flush(Gpu *g, int drain) {
   return rc;
 }
 
-static int gpu_frame(Gpu *g, const vp9hip_fe_frame *fr, int serial) {
+/* last: the frame is the last one of its packet.  One vpx_codec_decode call decodes every frame of a superframe and
+ * vpx_codec_get_frame then returns the LAST decoded frame if that one is shown (vp9/vp9_dx_iface.c decoder_decode /
+ * decoder_get_frame -> vp9_get_raw_frame: ready_for_new_data + cm->show_frame) — the lower spatial layers of a
+ * superframe are decoded, may carry show_frame, and are never put out. */
+static int gpu_frame(Gpu *g, const vp9hip_fe_frame *fr, int serial, int last) {
   if (fr->show_existing) {
     if (gpu_flush(g, 0)) return -1;
+    if (!last) return 0;
     if (vp9hip_decoder_sync(g->dec)) return -1; /* any earlier frame may be the one shown */
     return deliver(g->out, fr->show_slot, &fr->params, -1);
   }
@@ -274,7 +280,7 @@ static int gpu_frame(Gpu *g, const vp9hip_fe_frame *fr, int serial) {
    * out the previous frame's buffer, so nothing queued writes what is being fetched) */
   if (gpu_flush(g, 0)) return -1;
   g->pend = 1;
-  g->pend_slot = fr->show_frame ? fr->new_slot : -1;
+  g->pend_slot = (fr->show_frame && last) ? fr->new_slot : -1;
   g->pend_set = set;
   g->pend_params = *P;
   return serial ? gpu_flush(g, 1) : 0;
@@ -287,7 +293,7 @@ static void *gpu_main(void *arg) {
     while (!g->has && !g->quit) pthread_cond_wait(&g->cv, &g->mu);
     if (!g->has) break;
     pthread_mutex_unlock(&g->mu);
-    const int rc = g->failed ? 0 : gpu_frame(g, &g->frame, 0);
+    const int rc = g->failed ? 0 : gpu_frame(g, &g->frame, 0, g->frame_last);
     pthread_mutex_lock(&g->mu);
     if (rc) g->failed = 1;
     g->has = 0;
@@ -430,6 +436,8 @@ int main(int argc, char **argv) {
       uint32_t sizes[8];
       const int nf = vp9hip_fe_split_superframe(file + pos, psz, sizes);
       size_t off = 0;
+      int last_k = nf - 1;
+      while (last_k > 0 && nf > 1 && sizes[last_k] == 0) --last_k;
       for (int k = 0; k < nf && !rc_all; ++k) {
         if (nf > 1 && sizes[k] == 0) continue;
         vp9hip_fe_frame fr;
@@ -449,10 +457,11 @@ int main(int argc, char **argv) {
           while (g.has) pthread_cond_wait(&g.cv, &g.mu);
           if (g.failed) rc_all = 1;
           g.frame = fr;
+          g.frame_last = k == last_k;
           g.has = 1;
           pthread_cond_broadcast(&g.cv);
           pthread_mutex_unlock(&g.mu);
-        } else if (gpu_frame(&g, &fr, serial)) {
+        } else if (gpu_frame(&g, &fr, serial, k == last_k)) {
           rc_all = 1;
         }
         t_hand += now_s() - t0;
