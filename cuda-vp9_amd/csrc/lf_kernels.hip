@@ -301,6 +301,17 @@ __device__ __forceinline__ void lf_pass_h(Pix *tile, const unsigned *ctl, int x0
 // Every wait is bounded all the same: a row that gives up raises the context's error flag (vp9hip_sync reports it).
 constexpr int LF_SPIN_LIMIT = 1 << 18;  // x (s_sleep + L2 round trip) ~ a fraction of a second, then give up
 
+// err[0]: bit 0 a filter row gave up waiting, bit 1 an island did not fit; err[1..3]: what the FIRST wait that gave
+// up was waiting for — kind (1 island counter, 2 rows of the row above, 3 the workgroup's own filtering wave) |
+// plane << 8 | row << 16, superblock column, and the value it saw.  vp9hip_sync puts them into the error text.
+__device__ __forceinline__ void lf_give_up(int *err, int kind, int pl, int sr, int col, int seen) {
+  if (atomicOr(err, 1) == 0) {
+    err[1] = kind | (pl << 8) | (sr << 16);
+    err[2] = col;
+    err[3] = seen;
+  }
+}
+
 __device__ __forceinline__ unsigned ld_sc1(const unsigned *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -408,7 +419,8 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       while (!dead && __hip_atomic_load(&gate_done[r * sb_cols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(4);
         if (++spins > LF_SPIN_LIMIT) {
-          if (lane == 0) atomicOr(err, 1);
+          if (lane == 0)
+            lf_give_up(err, 1, pl, r, col, __hip_atomic_load(&gate_done[r * sb_cols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (need << 16));
           dead = true;
         }
       }
@@ -442,7 +454,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         if (__builtin_amdgcn_ballot_w64(!ok) == 0 || dead) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > LF_SPIN_LIMIT) {
-          if (lane == 0) atomicOr(err, 1);
+          if (lane == 0) lf_give_up(err, 2, pl, sr, sc, 0);
           dead = true;
         }
       }
@@ -559,7 +571,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       for (int spins = 0; flags[0] < (unsigned)(sc + 1); ++spins) {  // wave 0 of this workgroup: bounded all the same
         __builtin_amdgcn_s_sleep(1);
         if (spins > LF_SPIN_LIMIT) {
-          if (lane == 0) atomicOr(err, 1);
+          if (lane == 0) lf_give_up(err, 3, pl, sr, sc, (int)flags[0]);
           break;
         }
       }
@@ -626,7 +638,10 @@ __device__ __forceinline__ int draw_ticket(int *ticket, int *ticket_next) {
   __shared__ int s_ticket;
   if (threadIdx.x == 0) {
     const int t = atomicAdd(ticket, 1);
-    if (t == 0) *ticket_next = 0;  // the next launch's counter (launches of a context run one after the other)
+    // the next launch's counter (launches of a context run one after the other).  An atomic at agent scope like the
+    // draws themselves, and the two counters lie in cache lines of their own: a plain store would bring its line
+    // into this XCD's L2, and draws of this XCD served from that copy would hand out tickets twice.
+    if (t == 0) __hip_atomic_exchange(ticket_next, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_ticket = t;
     VP9HIP_STAMP_SLOT(t);
   }
@@ -690,8 +705,8 @@ __global__ __launch_bounds__(256, WALK_LF_WAVES) void walk_lf_kernel(const vp9hi
   const int start = k > 0 ? rp.pos[k - 1] + (k - 1) * planes : 0;
   if (k > 0 && b < start + planes) {
     const int sr = k - 1, pl = b - start;
-    if (sr == 0 && pl == 0)
-      for (int i = (int)threadIdx.x; i < n_gate; i += 256) gate_next[i] = 0;
+    if (sr == 0 && pl == 0)  // (write-through stores at agent scope, like every other access to the counters)
+      for (int i = (int)threadIdx.x; i < n_gate; i += 256) __hip_atomic_store(&gate_next[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     VP9HIP_STAMP(0);
     lf_row_entry<Pix, SH>(S.row, lfms, sb_cols, sb_rows, th, f, mi_rows, err, gate_done, gate_expected, hand, gen, sr, pl);
     VP9HIP_STAMP(7);
@@ -739,13 +754,14 @@ static int lf_handoff_buffer(vp9hip_ctx *ctx, const vp9hip_frame *frame, int sb_
 
 // The ticket counters of two consecutive launches (see draw_ticket): a launch counts in one and clears the other.
 static int lf_tickets(vp9hip_ctx *ctx, int **cur, int **nxt) {
+  constexpr int LINE = 64;  // ints: 256 bytes apart
   if (!ctx->lf_ticket) {
-    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_ticket, 2 * sizeof(int)));
-    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_ticket, 0, 2 * sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_ticket, 2 * LINE * sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_ticket, 0, 2 * LINE * sizeof(int)));
     ctx->lf_ticket_parity = 0;
   }
-  *cur = ctx->lf_ticket + ctx->lf_ticket_parity;
-  *nxt = ctx->lf_ticket + (ctx->lf_ticket_parity ^ 1);
+  *cur = ctx->lf_ticket + ctx->lf_ticket_parity * LINE;
+  *nxt = ctx->lf_ticket + (ctx->lf_ticket_parity ^ 1) * LINE;
   ctx->lf_ticket_parity ^= 1;
   return VP9HIP_OK;
 }
@@ -765,8 +781,8 @@ static int lf_prepare(vp9hip_ctx *ctx, const char *who, const vp9hip_lfm *d_lfm,
   // the error flag lives in an allocation of its own: it stays set until vp9hip_sync has reported it, however
   // many frames are enqueued behind the one that gave up
   if (!ctx->lf_err_flag) {
-    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_err_flag, sizeof(int)));
-    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_err_flag, 4 * sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, 4 * sizeof(int)));
   }
   ctx->lf_err_armed = true;
   return lf_handoff_buffer(ctx, frame, sb_rows, gen);
