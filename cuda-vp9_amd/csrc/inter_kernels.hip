@@ -121,41 +121,7 @@ __global__ __launch_bounds__(64) void inter_pred_kernel(const vp9hip_inter_task 
 }
 
 
-constexpr int FAST_THREADS = 256;  // 4 waves per workgroup: WG dispatch rate, not work, bounds tiny WGs
-
-// A tile's slot (16, 32 or 64 lanes) never straddles a wavefront, and a wave's LDS operations execute
-// in issue order: the stages of a tile only need the compiler pinned and lgkmcnt drained, not a
-// workgroup barrier — with s_barrier the four waves of a workgroup waited for the slowest one six
-// times per tile.
-__device__ __forceinline__ void slot_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local"); }
-
-// ---------------------------------------------------------------------------------------------
-// Fast path for 16-bit samples (high bitdepth, bd 8/10/12), unscaled references: the same tiling as
-// the 8-bit path with two samples per dword.
-//  stage   (h+7) x (TW+7) window from column x0-3 -> LDS, 16-byte chunks (8 samples)
-//  rows    lane = (window row, group of 4 outputs): 6 dwords = samples 4g..4g+11; output 4g+i is
-//          sum_k f[k]*s[4g+i+k]: even i use the dwords as they are, odd i the same dwords shifted by
-//          one sample (v_alignbit), four v_dot2_i32_i16 each; clipped to the bit depth (normative:
-//          vpx_convolve.c:311-335 highbd_convolve_horiz) and written TRANSPOSED to LDS
-//  cols    lane = (column, group of 4 output rows): the same form on the transposed intermediate
-// The 128-tap of phase 0 fits int16, so full-sample positions need no special case here.
 typedef short short2v __attribute__((ext_vector_type(2)));
-
-template <int W>
-struct Fast16Cfg {
-  static constexpr int TW = W >= 16 ? 16 : W;
-  static constexpr int HMAX = W == 4 ? 8 : (W == 8 ? 16 : (W == 16 ? 32 : 64));
-  static constexpr int TPT = (W / TW) * (HMAX / 16 ? HMAX / 16 : 1);
-  static constexpr int SL = TW == 16 ? 64 : (TW == 8 ? 32 : 16);
-  static constexpr int DC = TW / 4;                    // groups of 4 outputs per row
-  static constexpr int NCH = (TW + 7 + 7) / 8;         // 16-byte chunks per window row
-  static constexpr int PW = NCH * 16 + 8;              // window pitch in bytes (+8: the last group reads 6 dwords)
-  static constexpr int PT = 52;                        // transposed pitch in bytes: 23 rows + pad, 13 dwords (odd)
-  static constexpr int WIN_BYTES = 23 * PW;
-  static constexpr int T_BYTES = TW * PT + 8;
-  static constexpr int SLOT_BYTES = (WIN_BYTES + T_BYTES + 15) & ~15;
-};
-constexpr int FAST16_LDS = 18432;  // max over W of (FAST_THREADS / SL) * SLOT_BYTES (W = 4: 16 slots x 1136 B)
 
 __device__ __forceinline__ int dot8_16(unsigned s0, unsigned s1, unsigned s2, unsigned s3, const uint4 &f, int maxv) {
   short2v a, b;
@@ -167,146 +133,6 @@ __device__ __forceinline__ int dot8_16(unsigned s0, unsigned s1, unsigned s2, un
   acc >>= 7;
   return acc < 0 ? 0 : (acc > maxv ? maxv : acc);
 }
-
-// four consecutive outputs from six dwords (twelve samples)
-__device__ __forceinline__ void four_outputs(const unsigned *d, const uint4 &f, int maxv, int *o) {
-  const unsigned a01 = __builtin_amdgcn_alignbit(d[1], d[0], 16), a12 = __builtin_amdgcn_alignbit(d[2], d[1], 16);
-  const unsigned a23 = __builtin_amdgcn_alignbit(d[3], d[2], 16), a34 = __builtin_amdgcn_alignbit(d[4], d[3], 16);
-  const unsigned a45 = __builtin_amdgcn_alignbit(d[5], d[4], 16);
-  o[0] = dot8_16(d[0], d[1], d[2], d[3], f, maxv);
-  o[1] = dot8_16(a01, a12, a23, a34, f, maxv);
-  o[2] = dot8_16(d[1], d[2], d[3], d[4], f, maxv);
-  o[3] = dot8_16(a12, a23, a34, a45, f, maxv);
-}
-
-template <int W>
-__device__ __forceinline__ void inter_fast16_body(unsigned char *lds, int wg, const vp9hip_inter_task *__restrict__ tasks,
-                                                  int n_tasks, const RefSet &refs, const FrameDev &dstf) {
-  typedef Fast16Cfg<W> C;
-  constexpr int TW = C::TW;
-  constexpr int GW = FAST_THREADS / C::SL;
-  static_assert(GW * C::SLOT_BYTES <= FAST16_LDS, "LDS budget");
-  static_assert(TW * 4 == C::SL, "one column-pass item per lane");
-  const int g = threadIdx.x / C::SL, sl = threadIdx.x % C::SL;
-  const int wid = wg * GW + g;
-  const int ti = wid / C::TPT, tile = wid - ti * C::TPT;
-  const int tx = tile % (W / TW), ty = tile / (W / TW);
-  bool active = ti < n_tasks;
-  vp9hip_inter_task t;
-  if (active) t = tasks[ti];
-  active = active && ty * 16 < t.h;
-  unsigned char *win = lds + g * C::SLOT_BYTES;
-  unsigned char *T = win + C::WIN_BYTES;
-  const int plane = active ? t.plane : 0;
-  const int h = active ? min(16, (int)t.h - ty * 16) : 0;
-  const int filt = active ? (t.flags >> 1) & 7 : 0;
-  const int nref = active ? ((t.flags & 1) ? 2 : 1) : 0;
-  const int maxv = (1 << dstf.bit_depth) - 1;
-  uint16_t *dplane = (uint16_t *)dstf.plane[plane];
-  const int dstride = dstf.stride[plane];
-  const int dx = active ? t.dst_x + tx * TW : 0, dy = active ? t.dst_y + ty * 16 : 0;
-  const int vis_w = active ? min(TW, dstf.awidth[plane] - dx) : 0;
-  const int vis_h = active ? min(h, dstf.aheight[plane] - dy) : 0;
-  const int rows = h + 7;
-  const uint4 *taps = (const uint4 *)&kFilters[0][0][0];  // (f0,f1) (f2,f3) (f4,f5) (f6,f7) per (filter, phase)
-  int k0 = 0, k1 = 0, k2 = 0, k3 = 0;  // first prediction of a compound tile
-
-  for (int r = 0; r < 2; ++r) {
-    const bool on = active && r < nref && vis_w > 0 && vis_h > 0;
-    int x0 = 0, y0 = 0, subx = 0, suby = 0;
-    if (on) {
-      const int px = t.pos_x[r] + tx * TW * 16, py = t.pos_y[r] + ty * 16 * 16;
-      x0 = px >> 4;
-      y0 = py >> 4;
-      subx = px & 15;
-      suby = py & 15;
-      const FrameDev &rf = refs.f[t.ref[r]];
-      const uint16_t *src = (const uint16_t *)rf.plane[plane];
-      const int sstride = rf.stride[plane];
-      const int fw = rf.width[plane], fh = rf.height[plane];
-      const bool interior = x0 - 3 >= 0 && x0 - 3 + C::NCH * 8 <= fw && y0 - 3 >= 0 && y0 + h + 4 <= fh - 1;
-      if (interior) {
-        const uint16_t *base = src + (size_t)(y0 - 3) * sstride + (x0 - 3);
-        for (int i = sl; i < rows * C::NCH; i += C::SL) {
-          const int rr = i / C::NCH, ch = i - rr * C::NCH;
-          uint4 v;
-          __builtin_memcpy(&v, base + (size_t)rr * sstride + ch * 8, 16);
-          *(uint4 *)(win + rr * C::PW + ch * 16) = v;
-        }
-      } else {
-        uint16_t *w16 = (uint16_t *)win;
-        for (int i = sl; i < rows * (TW + 7); i += C::SL) {
-          const int rr = i / (TW + 7), cc = i - rr * (TW + 7);
-          int sx = x0 - 3 + cc, sy = y0 - 3 + rr;
-          sx = sx < 0 ? 0 : (sx > fw - 1 ? fw - 1 : sx);
-          sy = sy < 0 ? 0 : (sy > fh - 1 ? fh - 1 : sy);
-          w16[rr * (C::PW / 2) + cc] = src[(size_t)sy * sstride + sx];
-        }
-      }
-    }
-    slot_sync();
-    if (on) {
-      // rows -> T (transposed, clipped)
-      const uint4 f = taps[filt * 16 + subx];
-      const unsigned *win32 = (const unsigned *)win;
-      uint16_t *T16 = (uint16_t *)T;
-      for (int i = sl; i < rows * C::DC; i += C::SL) {
-        const int rr = i / C::DC, j = i - rr * C::DC;
-        const unsigned *wp = win32 + rr * (C::PW / 4) + 2 * j;
-        unsigned d[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = wp[k];
-        int o[4];
-        four_outputs(d, f, maxv, o);
-        uint16_t *tp = T16 + (4 * j) * (C::PT / 2) + rr;
-        tp[0] = (uint16_t)o[0];
-        tp[C::PT / 2] = (uint16_t)o[1];
-        tp[2 * (C::PT / 2)] = (uint16_t)o[2];
-        tp[3 * (C::PT / 2)] = (uint16_t)o[3];
-      }
-    }
-    slot_sync();
-    if (on) {
-      // columns -> destination: lane = (column c, output rows 4m..4m+3)
-      const uint4 f = taps[filt * 16 + suby];
-      const unsigned *T32 = (const unsigned *)T;
-      uint16_t *dst = dplane + (size_t)dy * dstride + dx;
-      const int i = sl;
-      const int m = i / TW, c = i - m * TW;
-      if (m < (h >> 2)) {
-        const unsigned *tp = T32 + c * (C::PT / 4) + 2 * m;
-        unsigned d[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = tp[k];
-        int o[4];
-        four_outputs(d, f, maxv, o);
-        if (c < vis_w) {
-          uint16_t *dd = dst + (size_t)(4 * m) * dstride + c;
-          const int y = 4 * m;
-          if (nref == 2 && r == 0) {
-            k0 = o[0]; k1 = o[1]; k2 = o[2]; k3 = o[3];
-          } else {
-            if (r == 1) {  // vpx_highbd_convolve_avg_c: ROUND_POWER_OF_TWO(dst + pred, 1)
-              o[0] = (k0 + o[0] + 1) >> 1; o[1] = (k1 + o[1] + 1) >> 1; o[2] = (k2 + o[2] + 1) >> 1; o[3] = (k3 + o[3] + 1) >> 1;
-            }
-            if (y + 0 < vis_h) dd[0] = (uint16_t)o[0];
-            if (y + 1 < vis_h) dd[dstride] = (uint16_t)o[1];
-            if (y + 2 < vis_h) dd[2 * dstride] = (uint16_t)o[2];
-            if (y + 3 < vis_h) dd[3 * dstride] = (uint16_t)o[3];
-          }
-        }
-      }
-    }
-    slot_sync();
-  }
-}
-
-// All five width classes in one launch: workgroups [wg_start[k], wg_start[k+1]) serve class k.
-struct FastPlan {
-  int wg_start[6];
-  int task_start[5];
-  int task_count[5];
-};
 
 // XCD-aware order inside a class.  Workgroup b runs on XCD b % 8 (round-robin dispatch; an affinity
 // assumption used for speed only) and each XCD has its own L2.  A class's tasks are in decode
@@ -573,31 +399,159 @@ int reg_wgs(int n) {
   return (int)(((long long)n * RegCfg<W, H>::SPT + per_wg - 1) / per_wg);
 }
 
-__global__ __launch_bounds__(FAST_THREADS) void inter_fast16_kernel(const vp9hip_inter_task *__restrict__ tasks,
-                                                                    FastPlan plan, RefSet refs, FrameDev dstf) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[FAST16_LDS];
-  const int b = blockIdx.x;
-  if (b < plan.wg_start[1])
-    inter_fast16_body<4>(lds, xcd_order(b, plan.wg_start[0], plan.wg_start[1]), tasks + plan.task_start[0],
-                         plan.task_count[0], refs, dstf);
-  else if (b < plan.wg_start[2])
-    inter_fast16_body<8>(lds, xcd_order(b, plan.wg_start[1], plan.wg_start[2]), tasks + plan.task_start[1],
-                         plan.task_count[1], refs, dstf);
-  else if (b < plan.wg_start[3])
-    inter_fast16_body<16>(lds, xcd_order(b, plan.wg_start[2], plan.wg_start[3]), tasks + plan.task_start[2],
-                          plan.task_count[2], refs, dstf);
-  else if (b < plan.wg_start[4])
-    inter_fast16_body<32>(lds, xcd_order(b, plan.wg_start[3], plan.wg_start[4]), tasks + plan.task_start[3],
-                          plan.task_count[3], refs, dstf);
-  else
-    inter_fast16_body<64>(lds, xcd_order(b, plan.wg_start[4], plan.wg_start[5]), tasks + plan.task_start[4],
-                          plan.task_count[4], refs, dstf);
+// ---------------------------------------------------------------------------------------------
+// Register path for 16-bit samples (bit depth 8 / 10 / 12 in uint16 frames), unscaled references: the form of
+// inter_reg_body with two samples per dword.  A lane owns TWO adjacent output columns (one destination dword per
+// row) of a strip of 4 or 8 rows; a task of width W takes W / 2 neighbouring lanes per strip.
+//  load    NR = strip + 7 window rows of ten samples (x0-3 .. x0+6) = five dwords each, row index clamped to the plane
+//  rows    output 0 from dwords 0..3, output 1 from the same ten samples shifted by one (v_alignbit_b32 x 4):
+//          2 x 4 v_dot2_i32_i16, clip, pack -> one dword per window row.  The phase-0 kernel {0,0,0,128,0,0,0,0}
+//          fits i16, so the identity needs no special case; the clip BETWEEN the passes is normative
+//          (vpx_convolve.c:355-375, highbd_convolve).
+//  cols    per column the window rows pair up two to a dword (v_perm_b32; even and odd starts), 4 dots per output
+//  out     (a + b + 1) >> 1 with the first prediction for a compound strip, one dword store per row
+// No LDS at all.  K-conv 2160p 10-bit 64x64: 36.3 us against 59.3 us for the LDS-staged tile form it replaced
+// (window staging, transposed intermediate, fences per stage), 16x16: 45.8 against 70.1 us.
+template <int W, int H>
+struct Reg16Cfg {
+  static constexpr int L = W / 2;            // lanes per strip
+  static constexpr int SH = H == 4 ? 4 : 8;  // rows per strip
+  static constexpr int SPT = H / SH;         // strips per task
+  static constexpr int NR = SH + 7;          // window rows of a strip
+};
+
+template <int W, int H>
+__device__ __forceinline__ void inter_reg16_body(int wg, const vp9hip_inter_task *__restrict__ tasks, int n_tasks,
+                                                 const RefSet &refs, const FrameDev &dstf) {
+  typedef Reg16Cfg<W, H> C;
+  constexpr int SH = C::SH, NR = C::NR;
+  const int gl = wg * REG_THREADS + threadIdx.x;
+  const int strip = gl / C::L, j = gl % C::L;
+  const int ti = strip / C::SPT, sub = strip % C::SPT;
+  const bool active = ti < n_tasks;
+  vp9hip_inter_task t;
+  if (active) t = tasks[ti];
+  const int plane = active ? t.plane : 0;
+  const int filt = active ? (t.flags >> 1) & 7 : 0;
+  const int nref = active ? ((t.flags & 1) ? 2 : 1) : 0;
+  const int dx = active ? t.dst_x + 2 * j : 0, dy = active ? t.dst_y + sub * SH : 0;
+  const int dstride = dstf.stride[plane];
+  const int maxv = (1 << dstf.bit_depth) - 1;
+  // awidth is a multiple of 8 and dx of 2: a lane's two columns are visible together or not at all
+  const int vis_h = (active && dx < dstf.awidth[plane]) ? min(SH, dstf.aheight[plane] - dy) : 0;
+  uint16_t *dst = (uint16_t *)dstf.plane[plane] + (size_t)dy * dstride + dx;
+  const uint4 *taps = (const uint4 *)&kFilters[0][0][0];  // (f0,f1) (f2,f3) (f4,f5) (f6,f7) per (filter, phase)
+  unsigned k[SH];  // first prediction of a compound strip
+#pragma unroll
+  for (int y = 0; y < SH; ++y) k[y] = 0;
+
+#pragma unroll 1
+  for (int r = 0; r < 2; ++r) {
+    const bool on = r < nref && vis_h > 0;
+    if (__builtin_amdgcn_ballot_w64(on) == 0) break;
+    if (on) {
+      const int px = r ? t.pos_x[1] : t.pos_x[0], py = r ? t.pos_y[1] : t.pos_y[0];
+      const int x0 = (px >> 4) + 2 * j, y0 = (py >> 4) + sub * SH;
+      const FrameDev &rf = refs.f[r ? t.ref[1] : t.ref[0]];
+      const uint16_t *src = (const uint16_t *)rf.plane[plane];
+      const int sstride = rf.stride[plane], fw = rf.width[plane], fh = rf.height[plane];
+      const uint4 fx = taps[filt * 16 + (px & 15)], fy = taps[filt * 16 + (py & 15)];
+      const int xs = x0 - 3;
+      unsigned hr[NR + 1];
+      const bool col_ok = xs >= 0 && xs + 10 <= fw;
+      if (__builtin_amdgcn_ballot_w64(!col_ok) == 0) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int sy = min(max(y0 - 3 + i, 0), fh - 1);
+          unsigned d[5];
+          __builtin_memcpy(d, src + (size_t)sy * sstride + xs, 20);
+          const int o0 = dot8_16(d[0], d[1], d[2], d[3], fx, maxv);
+          const int o1 = dot8_16(__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
+                                 __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(d[4], d[3], 16), fx, maxv);
+          hr[i] = (unsigned)o0 | ((unsigned)o1 << 16);
+        }
+      } else {  // a frame edge inside the window: every sample from its clamped column (libvpx's border emulation)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int sy = min(max(y0 - 3 + i, 0), fh - 1);
+          const uint16_t *rowp = src + (size_t)sy * sstride;
+          unsigned d[5];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            const unsigned a = rowp[min(max(xs + 2 * q, 0), fw - 1)], b = rowp[min(max(xs + 2 * q + 1, 0), fw - 1)];
+            d[q] = a | (b << 16);
+          }
+          const int o0 = dot8_16(d[0], d[1], d[2], d[3], fx, maxv);
+          const int o1 = dot8_16(__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
+                                 __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(d[4], d[3], 16), fx, maxv);
+          hr[i] = (unsigned)o0 | ((unsigned)o1 << 16);
+        }
+      }
+      hr[NR] = 0;
+      // columns: P[c][m] = rows (2m, 2m+1) of column c, Q[c][m] = rows (2m+1, 2m+2)
+      unsigned out[SH];
+#pragma unroll
+      for (int y = 0; y < SH; ++y) out[y] = 0;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const unsigned sel = c ? 0x07060302u : 0x05040100u;
+        unsigned P[(NR + 1) / 2], Q[NR / 2];
+#pragma unroll
+        for (int m = 0; m < (NR + 1) / 2; ++m) P[m] = __builtin_amdgcn_perm(hr[2 * m + 1], hr[2 * m], sel);
+#pragma unroll
+        for (int m = 0; m < NR / 2; ++m) Q[m] = __builtin_amdgcn_perm(hr[2 * m + 2], hr[2 * m + 1], sel);
+#pragma unroll
+        for (int y = 0; y < SH; ++y) {
+          const int m = y >> 1;
+          const int o = (y & 1) ? dot8_16(Q[m], Q[m + 1], Q[m + 2], Q[m + 3], fy, maxv) : dot8_16(P[m], P[m + 1], P[m + 2], P[m + 3], fy, maxv);
+          out[y] |= (unsigned)o << (16 * c);
+        }
+      }
+#pragma unroll
+      for (int y = 0; y < SH; ++y) {
+        // second reference of a compound strip: per sample (a + b + 1) >> 1 (vpx_highbd_convolve_avg_c); samples < 2^15,
+        // so the two halves of the dword do not carry into each other
+        const unsigned res = r == 1 ? ((k[y] + out[y] + 0x00010001u) >> 1) & 0x7fff7fffu : out[y];
+        const bool first = nref == 2 && r == 0;
+        k[y] = out[y];
+        if (!first && y < vis_h) *(unsigned *)(dst + (size_t)y * dstride) = res;
+      }
+    }
+  }
 }
 
-template <int W>
-int fast_wgs(int n) {
-  constexpr int GW = FAST_THREADS / Fast16Cfg<W>::SL;
-  return (n * Fast16Cfg<W>::TPT + GW - 1) / GW;
+#ifndef REG16_WAVES
+#define REG16_WAVES 3  // (4 fits 128 registers only with 45 spills: 37.7 against 36.3 us at K-conv 2160p 10-bit 64x64)
+#endif
+__global__ __launch_bounds__(REG_THREADS) __attribute__((amdgpu_waves_per_eu(REG16_WAVES, REG16_WAVES))) void inter_reg16_kernel(const vp9hip_inter_task *__restrict__ tasks,
+                                                                  RegPlan plan, RefSet refs, FrameDev dstf) {
+  const int b = blockIdx.x;
+  int k = 0;
+  while (k < REG_SHAPES - 1 && b >= plan.wg_start[k + 1]) ++k;
+  const int wg = xcd_order(b, plan.wg_start[k], plan.wg_start[k + 1]);
+  const vp9hip_inter_task *tk = tasks + plan.task_start[k];
+  const int n = plan.task_count[k];
+  switch (k) {
+    case 0: inter_reg16_body<4, 4>(wg, tk, n, refs, dstf); break;
+    case 1: inter_reg16_body<4, 8>(wg, tk, n, refs, dstf); break;
+    case 2: inter_reg16_body<8, 4>(wg, tk, n, refs, dstf); break;
+    case 3: inter_reg16_body<8, 8>(wg, tk, n, refs, dstf); break;
+    case 4: inter_reg16_body<8, 16>(wg, tk, n, refs, dstf); break;
+    case 5: inter_reg16_body<16, 8>(wg, tk, n, refs, dstf); break;
+    case 6: inter_reg16_body<16, 16>(wg, tk, n, refs, dstf); break;
+    case 7: inter_reg16_body<16, 32>(wg, tk, n, refs, dstf); break;
+    case 8: inter_reg16_body<32, 16>(wg, tk, n, refs, dstf); break;
+    case 9: inter_reg16_body<32, 32>(wg, tk, n, refs, dstf); break;
+    case 10: inter_reg16_body<32, 64>(wg, tk, n, refs, dstf); break;
+    case 11: inter_reg16_body<64, 32>(wg, tk, n, refs, dstf); break;
+    default: inter_reg16_body<64, 64>(wg, tk, n, refs, dstf); break;
+  }
+}
+
+template <int W, int H>
+int reg16_wgs(int n) {
+  constexpr int per_wg = REG_THREADS / Reg16Cfg<W, H>::L;  // strips per workgroup
+  return (int)(((long long)n * Reg16Cfg<W, H>::SPT + per_wg - 1) / per_wg);
 }
 
 int upload_taps(vp9hip_ctx *ctx) {
@@ -651,22 +605,22 @@ extern "C" int vp9hip_inter_pred_batch(vp9hip_ctx *ctx, const vp9hip_inter_task 
     hipLaunchKernelGGL(inter_pred_kernel<uint8_t>, dim3(fast_total), dim3(64), 0, ctx->stream, d_tasks, fast_total, rs, d);
     VP9HIP_CHECK(ctx, hipGetLastError());
   } else if (fast_total && dst->hbd) {
-    // 16-bit samples: the LDS-tiled kernel works per WIDTH (the shapes of one width are neighbours in the list)
-    const int by_w[5] = { class_count[0] + class_count[1], class_count[2] + class_count[3] + class_count[4],
-                          class_count[5] + class_count[6] + class_count[7], class_count[8] + class_count[9] + class_count[10],
-                          class_count[11] + class_count[12] };
-    FastPlan plan;
-    const int wgs16[5] = { fast_wgs<4>(by_w[0]), fast_wgs<8>(by_w[1]), fast_wgs<16>(by_w[2]), fast_wgs<32>(by_w[3]), fast_wgs<64>(by_w[4]) };
+    RegPlan plan;
+    const int wgs[REG_SHAPES] = { reg16_wgs<4, 4>(class_count[0]),    reg16_wgs<4, 8>(class_count[1]),   reg16_wgs<8, 4>(class_count[2]),
+                                  reg16_wgs<8, 8>(class_count[3]),    reg16_wgs<8, 16>(class_count[4]),  reg16_wgs<16, 8>(class_count[5]),
+                                  reg16_wgs<16, 16>(class_count[6]),  reg16_wgs<16, 32>(class_count[7]), reg16_wgs<32, 16>(class_count[8]),
+                                  reg16_wgs<32, 32>(class_count[9]),  reg16_wgs<32, 64>(class_count[10]), reg16_wgs<64, 32>(class_count[11]),
+                                  reg16_wgs<64, 64>(class_count[12]) };
     int acc_w = 0, acc_t = 0;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < REG_SHAPES; ++k) {
       plan.wg_start[k] = acc_w;
       plan.task_start[k] = acc_t;
-      plan.task_count[k] = by_w[k];
-      acc_w += wgs16[k];
-      acc_t += by_w[k];
+      plan.task_count[k] = class_count[k];
+      acc_w += wgs[k];
+      acc_t += class_count[k];
     }
-    plan.wg_start[5] = acc_w;
-    hipLaunchKernelGGL(inter_fast16_kernel, dim3(acc_w), dim3(FAST_THREADS), 0, ctx->stream, d_tasks, plan, rs, d);
+    plan.wg_start[REG_SHAPES] = acc_w;
+    hipLaunchKernelGGL(inter_reg16_kernel, dim3(acc_w), dim3(REG_THREADS), 0, ctx->stream, d_tasks, plan, rs, d);
     VP9HIP_CHECK(ctx, hipGetLastError());
   } else if (fast_total) {
     RegPlan plan;

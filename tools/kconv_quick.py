@@ -14,7 +14,7 @@ ctx = pkg.Context(0)
 rng = np.random.default_rng(7)
 out = []
 for (W, H) in ((3840, 2160),):
-    for bd in (8,):
+    for bd in ((int(os.environ["KCONV_BD"]),) if os.environ.get("KCONV_BD") else (8,)):
         dt = np.uint16 if bd > 8 else np.uint8
         refs = []
         for r in range(3):
