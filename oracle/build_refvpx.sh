@@ -116,7 +116,15 @@ if [ -f "$ROOT/shim/build/libvp9hip_shim.so" ]; then
       -L"$ROOT/shim/build" -lvp9hip_shim -L"$ROOT/cuda-vp9_amd" -lvp9hip $RP $LINK
   g++ -o "$ROOT/shim/build/vpxdec_hip_mt" $DEC_TOOLS "$OUT/decodeframe_patched_mt.o" "$OUT/decoder_patched.o" "$OUT/libvpxfull.a" \
       -L"$ROOT/shim/build" -lvp9hip_shim -L"$ROOT/cuda-vp9_amd" -lvp9hip $RP $LINK
-  echo "built shim/build/vpxdec_hipA, vpxdec_hip, vpxdec_hip_mt"
+  # bring-up mode: the reference's CPU reconstruction with its run-time dispatch pointers assigned to the _hip twins (E13)
+  TMP2="$(mktemp -d)"
+  python3 "$HERE/patch_decodeframe.py" --decoder-c "$L/vp9/decoder/vp9_decoder.c" "$TMP2/vp9_decoder_rtcd.c" --rtcd
+  gcc -std=gnu99 $CF -include "$OUT/simd_to_c.h" -c "$TMP2/vp9_decoder_rtcd.c" -o "$OUT/decoder_rtcd.o"
+  rm -rf "$TMP2"
+  gcc -std=gnu99 $CF -include "$OUT/simd_to_c.h" -c "$ROOT/shim/vp9hip_rtcd_install.c" -o "$OUT/rtcd_install.o"
+  g++ -o "$ROOT/shim/build/vpxdec_rtcd" $DEC_TOOLS "$OUT/decodeframe_patched.o" "$OUT/decoder_rtcd.o" "$OUT/rtcd_install.o" \
+      "$OUT/ref_stream_wraps.o" "$OUT/libvpxfull.a" -L"$ROOT/cuda-vp9_amd" -lvp9hip $RP $LINK
+  echo "built shim/build/vpxdec_hipA, vpxdec_hip, vpxdec_hip_mt, vpxdec_rtcd"
 else
   echo "build_refvpx: shim/build/libvp9hip_shim.so absent — run make -C shim first for vpxdec_hip*"
 fi

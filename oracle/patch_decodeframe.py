@@ -28,6 +28,8 @@ Edits (decode_tiles = vp9_decodeframe.c:2303-2639):
       host-to-device copy a staged, synchronous one)
   E8  (other file: `patch_decodeframe.py --decoder-c <vp9_decoder.c> <out>`) vp9_decoder_remove calls
       vp9hip_shim_release(pbi): GPU state does not outlive the decoder (`vpxdec --loops=N`)
+  E13 (other file, `--decoder-c ... --rtcd`) initialize_dec (vp9_decoder.c:39-49) calls vp9hip_install_rtcd()
+      (shim/vp9hip_rtcd_install.c): the block-level integration, run-time dispatch pointers -> _hip twins
   E9  vp9hip_shim_mark(pbi, k) at five points of decode_tiles: where the host time of a frame goes, printed
       with VP9HIP_SHIM_TRACE=1 (no effect otherwise)
   E10 (--mt) tile-parallel entropy stage: one thread per tile column with private list segments /
@@ -63,6 +65,12 @@ def patch_decoder_c(src, dst):
     t = replace_once(t, "void vp9_decoder_remove(VP9Decoder *pbi) {\n  int i;\n\n  if (!pbi) return;\n",
                      "#include \"vp9hip_libvpx_shim.h\"\nvoid vp9_decoder_remove(VP9Decoder *pbi) {\n  int i;\n\n"
                      "  if (!pbi) return;\n  vp9hip_shim_release(pbi);\n", "E8 vp9_decoder_remove")
+    if "--rtcd" in sys.argv:
+        # E13 (bring-up mode, shim/build/vpxdec_rtcd only): the run-time dispatch pointers get their _hip twins right after
+        # the reference's own setup and before vp9_init_intra_predictors copies them into its tables
+        t = replace_once(t, "    vpx_scale_rtcd();\n    vp9_init_intra_predictors();\n",
+                         "    vpx_scale_rtcd();\n    { extern void vp9hip_install_rtcd(void); vp9hip_install_rtcd(); }\n"
+                         "    vp9_init_intra_predictors();\n", "E13 initialize_dec")
     open(dst, "w", encoding="utf-8", errors="surrogateescape").write(t)
 
 

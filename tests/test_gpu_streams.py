@@ -85,3 +85,27 @@ def test_baseline_sized_stream_md5(name):
         pytest.skip(f"tests/streams_big/{name}.ivf not generated (make_streams.py --big)")
     check(HIP, BIG, name)
     check(HIP_MT, BIG, name)  # 8 / 16 / 16 / 4 tile columns
+
+
+RTCD = os.path.join(ROOT, "shim", "build", "vpxdec_rtcd")
+
+
+@pytest.mark.parametrize("name", ["s352_arf", "s350_8"])
+def test_stream_md5_rtcd_pointer_dispatch(name):
+    """The block-level integration: the reference's run-time dispatch POINTERS assigned to the `_hip` twins
+    (shim/vp9hip_rtcd_install.c, called from initialize_dec — oracle/patch_decodeframe.py E13 — where the reference's own
+    setup_rtcd_internal assigns SIMD variants, vpx-master/vpx_dsp_rtcd.h:2074).  vpxdec_rtcd is the reference's vpxdec
+    with its CPU reconstruction; its directional intra predictors and 16-wide loop filters run on the GPU one block
+    at a time (bring-up mode: slow), and the stream's MD5s must still be the golden ones."""
+    if not os.path.exists(RTCD):
+        pytest.fail(f"{RTCD} missing: run oracle/build_refvpx.sh in the development container")
+    want = golden(os.path.join(SMALL, name + ".md5"))
+    e = dict(os.environ, VP9HIP_RTCD_TRACE="1")
+    r = subprocess.run([RTCD, "--rawvideo", "--md5", "-o", "img-%wx%h-%4.i420", os.path.join(SMALL, name + ".ivf")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=e, timeout=900)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-2000:]
+    got = [l for l in out.splitlines() if re.match(r"^[0-9a-f]{32}  img-", l)]
+    assert got == want
+    m = re.search(r"vp9hip: (\d+) rtcd pointers were assigned to _hip twins; last twin error: \"(.*)\"", out)
+    assert m and int(m.group(1)) >= 15 and m.group(2) == "", out[-600:]
