@@ -208,6 +208,8 @@ __device__ __forceinline__ void lf_pass_v(Pix *tile, const unsigned *ctl, int y0
   const unsigned *vE = ctl, *vI = ctl + 64;
   if (lane < n && y0 + lane < ph && (lane >> 3) < mrows) {
     const int mr = lane >> 3;
+    // (the compiler reads and writes the row's samples a dword at a time and unpacks / packs them; one LDS operation
+    // per sample instead — no packing in the chain — measured 1669 against 2133 frames/s)
     Pix *row = tile + (8 + lane) * TP;
     int w[16], nxt[8];
 #pragma unroll
