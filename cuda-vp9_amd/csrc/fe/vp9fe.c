@@ -207,6 +207,9 @@ struct vp9hip_fe {
   int trace;     /* VP9HIP_FE_TRACE: where a frame's parse time goes, printed when the front-end is destroyed */
   double tr_total, tr_head, tr_tiles, tr_tile_sum, tr_tile_max, tr_tail;
   int tr_frames;
+  int narrow_slots; /* try int16 coefficient slots first (vp9hip_fe_set_narrow_slots) */
+  int narrow_limit; /* 0, or (tests) a smaller magnitude that already counts as "does not fit" */
+  int wide_frames;  /* frames that had to be parsed again with int32 slots */
   int checksums; /* VP9HIP_FE_CHECKSUMS: per-block checksum of eobs + coefficients in reserved2 (tests/test_fe_blocks.py) */
 
   /* stream state that outlives a frame */
@@ -768,6 +771,8 @@ typedef struct TileCtx {
   int32_t *cf[3], *cf_base[3];
   int32_t scratch[1024];
   int corrupt;
+  int narrow;           /* slots are written as int16 (vp9hip_coeff_layout.narrow) ... */
+  uint32_t out_of_range; /* ... and this is non-zero once a coefficient did not fit */
   /* the block being read */
   vp9hip_block *cur;
   const vp9hip_block *above, *left;
@@ -1690,7 +1695,20 @@ static int read_block_tokens(TileCtx *t) {
           const int ext = vp9hip_coeff_extent(eob, (p || tx == TX_32X32) ? 0 : tx_type, tx);
           if (fe->checksums)
             for (int i = 0; i < ext; ++i) sum += (uint32_t)t->scratch[i] * (uint32_t)(i + 1);
-          memcpy(t->cf[p], t->scratch, sizeof(int32_t) * (size_t)ext);
+          if (t->narrow) {
+            /* int16 slots at the same offsets (in coefficients): the array is an int16 array for this frame */
+            int16_t *d16 = (int16_t *)fe->coef[p] + (t->cf[p] - fe->coef[p]);
+            uint32_t bad = 0;
+            for (int i = 0; i < ext; ++i) {
+              const int32_t v = t->scratch[i];
+              d16[i] = (int16_t)v;
+              bad |= (uint32_t)(v + 32768) >> 16;
+              if (fe->narrow_limit) bad |= (uint32_t)((v < 0 ? -v : v) >= fe->narrow_limit);
+            }
+            t->out_of_range |= bad;
+          } else {
+            memcpy(t->cf[p], t->scratch, sizeof(int32_t) * (size_t)ext);
+          }
           t->cf[p] += ext;
           /* the clearing rule of vp9_decodeframe.c:960-967 — what the extent is defined by */
           if (eob == 1)
@@ -2054,6 +2072,13 @@ static void use_set(vp9hip_fe *fe, int k) {
   }
 }
 
+void vp9hip_fe_set_narrow_slots(vp9hip_fe *fe, int on) {
+  if (!fe) return;
+  fe->narrow_slots = on != 0;
+  fe->narrow_limit = on > 1 ? on : 0; /* (tests: the fall-back to int32 slots on ordinary streams) */
+}
+int vp9hip_fe_wide_frames(const vp9hip_fe *fe) { return fe ? fe->wide_frames : 0; }
+
 void vp9hip_fe_destroy(vp9hip_fe *fe) {
   if (!fe) return;
   if (fe->trace && fe->tr_frames)
@@ -2269,38 +2294,56 @@ int vp9hip_fe_parse(vp9hip_fe *fe, const uint8_t *data, size_t size, vp9hip_fe_f
         p += sz;
       }
   }
-  /* per-frame context reset (decode_tiles :2358-2362) */
-  for (int p = 0; p < 3; ++p) memset(fe->above_nz[p], 0, (size_t)fe->ctx_cols * 2 + 32);
-  memset(fe->above_part, 0, (size_t)fe->ctx_cols + 16);
-  memset(fe->grid, 0xff, sizeof(int32_t) * (size_t)fe->mi_rows * fe->mi_cols);
   const int collect = !h->frame_parallel;
   const int ctx_rows = (fe->mi_rows + 7) & ~7;
-  for (int c = 0; c < tile_cols; ++c) {
-    TileCtx *t = &jobs[c].tc;
-    t->fe = fe;
-    t->tile_col = c;
-    t->col_start = tile_offset(c, fe->mi_cols, h->log2_tile_cols);
-    t->col_end = tile_offset(c + 1, fe->mi_cols, h->log2_tile_cols);
-    t->counts = collect ? &jobs[c].counts : NULL;
-    t->seg_first = t->blk = fe->seg_blocks + (size_t)t->col_start * fe->mi_rows;
-    t->off = fe->seg_off;
-    for (int p = 0; p < 3; ++p) {
-      const int ss = p ? fe->ss_x : 0;
-      jobs[c].cf_start[p] = (int64_t)((t->col_start * 8) >> ss) * ((ctx_rows * 8) >> ss);
-      t->cf[p] = t->cf_base[p] = fe->coef[p] + jobs[c].cf_start[p];
+  double tr1 = 0.0, tr2 = 0.0;
+  int total = 0;
+  /* Coefficient slots: int16 first when the caller asked for them (half the bytes on the way to the device).  The
+   * reference keeps 32-bit coefficients (vpx_dsp/vpx_dsp_common.h:36-37; vp9_detokenize.c:243-250 stores whatever
+   * (value * dequantiser) / 2 gives), so a frame in which a single coefficient does not fit is parsed AGAIN with
+   * int32 slots: the tile jobs only write per-frame state (their lists, the segment map and motion vectors of THIS
+   * frame, their counts), so running them twice gives the same result as running them once. */
+  for (int narrow = fe->narrow_slots; ; narrow = 0) {
+    /* per-frame context reset (decode_tiles :2358-2362) */
+    for (int p = 0; p < 3; ++p) memset(fe->above_nz[p], 0, (size_t)fe->ctx_cols * 2 + 32);
+    memset(fe->above_part, 0, (size_t)fe->ctx_cols + 16);
+    memset(fe->grid, 0xff, sizeof(int32_t) * (size_t)fe->mi_rows * fe->mi_cols);
+    for (int c = 0; c < tile_cols; ++c) {
+      TileCtx *t = &jobs[c].tc;
+      memset(t, 0, sizeof(*t));
+      memset(&jobs[c].counts, 0, sizeof(jobs[c].counts));
+      t->fe = fe;
+      t->narrow = narrow;
+      t->tile_col = c;
+      t->col_start = tile_offset(c, fe->mi_cols, h->log2_tile_cols);
+      t->col_end = tile_offset(c + 1, fe->mi_cols, h->log2_tile_cols);
+      t->counts = collect ? &jobs[c].counts : NULL;
+      t->seg_first = t->blk = fe->seg_blocks + (size_t)t->col_start * fe->mi_rows;
+      t->off = fe->seg_off;
+      for (int p = 0; p < 3; ++p) {
+        const int ss = p ? fe->ss_x : 0;
+        jobs[c].cf_start[p] = (int64_t)((t->col_start * 8) >> ss) * ((ctx_rows * 8) >> ss);
+        t->cf[p] = t->cf_base[p] = fe->coef[p] + jobs[c].cf_start[p];
+      }
     }
-  }
-  const double tr1 = fe->trace ? fe_now() : 0.0;
-  run_jobs(fe, tile_cols);
-  const double tr2 = fe->trace ? fe_now() : 0.0;
-  int corrupt = 0, total = 0;
-  for (int c = 0; c < tile_cols; ++c) {
-    corrupt |= jobs[c].tc.corrupt;
-    total += jobs[c].n_blocks;
-  }
-  if (corrupt) {
-    fe->need_resync = 1;
-    FE_FAIL(fe, "decode failed: frame data is corrupted");
+    tr1 = fe->trace ? fe_now() : 0.0;
+    run_jobs(fe, tile_cols);
+    tr2 = fe->trace ? fe_now() : 0.0;
+    int corrupt = 0;
+    uint32_t out_of_range = 0;
+    total = 0;
+    for (int c = 0; c < tile_cols; ++c) {
+      corrupt |= jobs[c].tc.corrupt;
+      out_of_range |= jobs[c].tc.out_of_range;
+      total += jobs[c].n_blocks;
+    }
+    if (corrupt) {
+      fe->need_resync = 1;
+      FE_FAIL(fe, "decode failed: frame data is corrupted");
+    }
+    out->layout.narrow = narrow;
+    if (!narrow || !out_of_range) break;
+    ++fe->wide_frames;
   }
 
   /* one list in decode order: superblock raster order (= the serial loop of decode_tiles :2388-2430) */

@@ -305,7 +305,7 @@ static void *gpu_main(void *arg) {
 
 int main(int argc, char **argv) {
   const char *path = NULL, *pattern = NULL;
-  int do_md5 = 0, noblit = 0, fetch = 0, summary = 0, loops = 1, threads = 0, serial = 0, stats = 0, parse_only = 0, device = 0;
+  int do_md5 = 0, noblit = 0, fetch = 0, summary = 0, loops = 1, threads = 0, serial = 0, stats = 0, parse_only = 0, device = 0, wide_slots = 0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--md5"))
       do_md5 = 1;
@@ -323,6 +323,8 @@ int main(int argc, char **argv) {
       parse_only = 1;
     else if (!strcmp(argv[i], "--rawvideo") || !strcmp(argv[i], "--i420"))
       ;
+    else if (!strcmp(argv[i], "--wide-slots"))
+      wide_slots = 1; /* keep int32 coefficient slots (the reference's width) for every frame */
     else if (!strncmp(argv[i], "--loops=", 8))
       loops = atoi(argv[i] + 8);
     else if (!strncmp(argv[i], "--threads=", 10))
@@ -339,7 +341,7 @@ int main(int argc, char **argv) {
     }
   }
   if (!path) {
-    fprintf(stderr, "usage: vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--device=N] [--serial] [--stats] [--parse-only] file.ivf\n");
+    fprintf(stderr, "usage: vp9hip_dec [--md5] [-o pattern] [--noblit] [--fetch] [--summary] [--loops=N] [--threads=N] [--device=N] [--serial] [--stats] [--wide-slots] [--parse-only] file.ivf\n");
     return 2;
   }
   if (!pattern && !do_md5) noblit = 1;
@@ -409,6 +411,7 @@ int main(int argc, char **argv) {
   for (int loop = 0; loop < loops && !rc_all; ++loop) {
     vp9hip_fe *fe = NULL; /* a new stream per loop */
     if (vp9hip_fe_create(&fe, pinned_alloc, pinned_free, dec, threads)) return 1;
+    vp9hip_fe_set_narrow_slots(fe, !wide_slots); /* int16 coefficient slots wherever a frame's coefficients fit */
     Output out;
     memset(&out, 0, sizeof(out));
     out.dec = dec;
@@ -488,6 +491,9 @@ int main(int argc, char **argv) {
               "fetch %.3f ms, hash/write %.3f ms\n",
               1e3 * t_parse / frames_in, 1e3 * t_hand / frames_in, 1e3 * g.t_begin / frames_in, 1e3 * out.t_fetch / frames_in,
               1e3 * out.t_hash / frames_in);
+    if (stats && frames_in)
+      fprintf(stderr, "vp9hip_dec: coefficient slots: %s; %d of %d frames parsed again with int32 slots (a coefficient outside int16)\n",
+              wide_slots ? "int32" : "int16 where a frame's coefficients fit", vp9hip_fe_wide_frames(fe), frames_in);
     for (int p = 0; p < 3; ++p)
       if (out.host[p]) vp9hip_decoder_host_free(dec, out.host[p]);
     vp9hip_decoder_sync(dec);

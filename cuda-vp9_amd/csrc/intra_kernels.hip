@@ -262,7 +262,7 @@ __device__ __forceinline__ void slot_sync() { __builtin_amdgcn_fence(__ATOMIC_SE
 template <typename Pix, bool HBD>
 __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 * TPITCH],
                                             const vp9hip_intra_task *__restrict__ tasks, int index, bool active,
-                                            const int32_t *__restrict__ coeffs, const FrameDev &f) {
+                                            const txfm::Coefs &coeffs, const FrameDev &f) {
   const int slot = threadIdx.x / SLOT, t = threadIdx.x % SLOT;
   vp9hip_intra_task tk;
   memset(&tk, 0, sizeof(tk));
@@ -272,7 +272,7 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
   const bool lossless = tk.tx_type & 0x80;
   const bool identity = tk.tx_type & 0x40;  // the "coefficients" are already the residual
   // coded: residual present; eob<=1 blocks take the DC-only forms (vp9_idct.c:119-204)
-  const bool coded = active && coeffs != nullptr && tk.eob > 0;
+  const bool coded = active && coeffs.p != nullptr && tk.eob > 0;
   int *E = edge[slot] + EOFF;
   int *tile = tiles[slot];
   int dc_kind = 0, dc_coeff = 0;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
       }
     }
     if (coded) {
-      const int32_t *src = coeffs + tk.coeff_off;
+      const txfm::CoefAt src = txfm::at(coeffs, tk.coeff_off);
       if (!identity) {
         if (!lossless && ((tk.tx_type & 3) == 0 || bs == 32) && (bs == 4 ? tk.eob <= 1 : tk.eob == 1)) dc_kind = 1;
         if (lossless && tk.eob <= 1) dc_kind = 2;
@@ -492,7 +492,7 @@ __device__ __forceinline__ void store_resid_col(short *dst, int pitch, const int
 // the column pass), 256 / N blocks per pass (16x16: 16, 32x32: 4 — one per wavefront).  A block's lanes lie inside one
 // wavefront, whose LDS operations execute in order: a fence per stage is enough (slot_sync).
 template <int N, bool HBD>
-__device__ __forceinline__ void island_residual_pass(IslandLds &S, int first, int count, const int32_t *__restrict__ coeffs) {
+__device__ __forceinline__ void island_residual_pass(IslandLds &S, int first, int count, const txfm::Coefs &coeffs) {
   constexpr int PITCH = N + 1;
   constexpr int BPP = N == 32 ? 4 : 256 / N;      // blocks per pass
   constexpr int LPB = N == 32 ? 64 : N;           // lanes a block owns (32x32: a wavefront, half of it idle)
@@ -506,7 +506,7 @@ __device__ __forceinline__ void island_residual_pass(IslandLds &S, int first, in
     const int kind = resid_kind(tk);
     const bool lossless = tk.tx_type & 0x80;
     const int tt = N == 32 ? 0 : (tk.tx_type & 3);
-    const int32_t *src = coeffs + tk.coeff_off;
+    const txfm::CoefAt src = txfm::at(coeffs, tk.coeff_off);
     const int pl = tk.plane, pitch = S.pitch[pl];
     short *dst = &S.tile[S.idx0[pl] + (int)tk.y * pitch + (int)tk.x + t];
     const bool full = active && kind == 0;
@@ -546,7 +546,7 @@ __device__ __forceinline__ void island_residual_pass(IslandLds &S, int first, in
 template <typename Pix, bool HBD>
 __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra_task *__restrict__ tasks,
                                                 const vp9hip_intra_island &isl, const int32_t *__restrict__ wave_off,
-                                                const int32_t *__restrict__ coeffs, const FrameDev &f,
+                                                const txfm::Coefs &coeffs, const FrameDev &f,
                                                 int *__restrict__ sb_done, int sb_cols) {
   const int tid = threadIdx.x;
   const int32_t *wo = wave_off + isl.wave_off_start;
@@ -569,7 +569,7 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
     atomicMax(&S.box[pl][2], (int)tk.x + bs);
     atomicMax(&S.box[pl][3], (int)tk.y + bs);
     if (tk.plane > 2 || tk.tx_size > 3 || (tk.flags & 8)) S.bad = 1;  // (raw edges: the rtcd twins' wave launches only)
-    if (coeffs != nullptr && tk.eob > 0) atomicAdd(&S.cnt[tk.tx_size & 3], 1);
+    if (coeffs.p != nullptr && tk.eob > 0) atomicAdd(&S.cnt[tk.tx_size & 3], 1);
     if (sb_done != nullptr && (tk.reserved & 1)) {
       // chroma subsampling from the plane sizes (4:2:0, 4:4:4 or single-plane frames)
       const int sx = tk.plane && f.awidth[pl] < f.awidth[0], sy = tk.plane && f.aheight[pl] < f.aheight[0];
@@ -604,7 +604,7 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
   const int wave = tid >> 6, lane = tid & 63;
   // ---- 2. the window, four samples per lane and load (aligned: block positions are multiples of 4, so is the plane's
   // start in memory); the indices of the coded blocks, size by size, ride along
-  if (coeffs != nullptr)
+  if (coeffs.p != nullptr)
     for (int i = tid; i < n; i += 256)
       if (S.tasks[i].eob > 0) S.order[atomicAdd(&S.fill[S.tasks[i].tx_size & 3], 1)] = (short)i;
 #pragma unroll 1
@@ -641,7 +641,7 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
   __syncthreads();
   VP9HIP_STAMP(2);
   // ---- 3. residuals, size by size
-  if (coeffs != nullptr) {
+  if (coeffs.p != nullptr) {
     int first = 0;
     if (S.cnt[0]) island_residual_pass<4, HBD>(S, first, S.cnt[0], coeffs);
     first += S.cnt[0];
@@ -715,7 +715,7 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
       }
       slot_sync();
       if (active) {
-        const bool coded = coeffs != nullptr && tk.eob > 0;
+        const bool coded = coeffs.p != nullptr && tk.eob > 0;
         short *blk = &S.tile[idx0 + y * pitch + x];
         // one loop per mode (the mode is the same for the 32 lanes of a slot): the compiler overlaps the LDS reads of
         // consecutive samples, which it cannot do across a switch inside the loop
@@ -793,7 +793,7 @@ __device__ __forceinline__ bool island_lds_body(IslandLds &S, const vp9hip_intra
 // One launch per dependency wave of the whole frame (deep structures: key frames).
 template <typename Pix, bool HBD>
 __global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task *__restrict__ tasks, int first,
-                                                         int count, const int32_t *__restrict__ coeffs, FrameDev f) {
+                                                         int count, txfm::Coefs coeffs, FrameDev f) {
   __shared__ int edge[SLOTS][ESIZE];
   __shared__ int tiles[SLOTS][32 * TPITCH];
   const int ti = blockIdx.x * SLOTS + threadIdx.x / SLOT;
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const vp9hip_intra_task
 template <typename Pix, bool HBD>
 __device__ __forceinline__ void island_mem_body(IslandMemLds &M, const vp9hip_intra_task *__restrict__ tasks,
                                                 const vp9hip_intra_island &isl, const int32_t *__restrict__ wave_off,
-                                                const int32_t *__restrict__ coeffs, const FrameDev &f) {
+                                                const txfm::Coefs &coeffs, const FrameDev &f) {
   // task j of a chunk goes to wavefront j % 4 (see island_lds_body)
   const int slot = ((threadIdx.x / SLOT) & 1) * (SLOTS / 2) + (threadIdx.x / SLOT) / 2;
   const int32_t *wo = wave_off + isl.wave_off_start;
@@ -831,7 +831,7 @@ template <typename Pix, bool HBD>
 __global__ __launch_bounds__(256) void intra_island_kernel(const vp9hip_intra_task *__restrict__ tasks,
                                                            const vp9hip_intra_island *__restrict__ islands,
                                                            const int32_t *__restrict__ wave_off,
-                                                           const int32_t *__restrict__ coeffs, FrameDev f) {
+                                                           txfm::Coefs coeffs, FrameDev f) {
   __shared__ IslandAnyLds S;
   if (threadIdx.x == 0) VP9HIP_STAMP_SLOT((int)blockIdx.x);
   const vp9hip_intra_island isl = islands[blockIdx.x];
@@ -853,12 +853,13 @@ extern "C" int vp9hip_intra_pred_islands(vp9hip_ctx *ctx, const vp9hip_intra_tas
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_islands: bad argument");
   if (n_islands == 0) return VP9HIP_OK;
   const FrameDev f = to_dev(frame);
+  const txfm::Coefs cf = { d_coeffs, ctx->coeff16 };
   if (frame->hbd)
     hipLaunchKernelGGL((intra_island_kernel<uint16_t, true>), dim3(n_islands), dim3(256), 0, ctx->stream, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, f);
+                       d_wave_off, cf, f);
   else
     hipLaunchKernelGGL((intra_island_kernel<uint8_t, false>), dim3(n_islands), dim3(256), 0, ctx->stream, d_tasks, d_islands,
-                       d_wave_off, d_coeffs, f);
+                       d_wave_off, cf, f);
   VP9HIP_CHECK(ctx, hipGetLastError());
   return VP9HIP_OK;
 }
@@ -870,6 +871,7 @@ extern "C" int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task 
   if (!d_tasks || !wave_start || n_waves < 0 || !frame_ok(frame))
     VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_waves: bad argument");
   const FrameDev f = to_dev(frame);
+  const txfm::Coefs cf = { d_coeffs, ctx->coeff16 };
   for (int w = 0; w < n_waves; ++w) {
     const int first = wave_start[w], count = wave_start[w + 1] - first;
     if (count < 0) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_intra_pred_waves: wave_start not monotonic");
@@ -877,10 +879,10 @@ extern "C" int vp9hip_intra_pred_waves(vp9hip_ctx *ctx, const vp9hip_intra_task 
     const int grid = (count + SLOTS - 1) / SLOTS;
     if (frame->hbd)
       hipLaunchKernelGGL((intra_wave_kernel<uint16_t, true>), dim3(grid), dim3(256), 0, ctx->stream, d_tasks, first,
-                         count, d_coeffs, f);
+                         count, cf, f);
     else
       hipLaunchKernelGGL((intra_wave_kernel<uint8_t, false>), dim3(grid), dim3(256), 0, ctx->stream, d_tasks, first,
-                         count, d_coeffs, f);
+                         count, cf, f);
   }
   VP9HIP_CHECK(ctx, hipGetLastError());
   return VP9HIP_OK;

@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256, WALK_LF_WAVES) void walk_lf_kernel(const vp9hi
                                                       int *gate_next, int n_gate, const int *gate_expected,
                                                       const vp9hip_intra_task *__restrict__ tasks,
                                                       const vp9hip_intra_island *__restrict__ islands,
-                                                      const int32_t *__restrict__ wave_off, const int32_t *__restrict__ coeffs,
+                                                      const int32_t *__restrict__ wave_off, txfm::Coefs coeffs,
                                                       lf_granule *hand, unsigned gen, RowPos rp, int *ticket,
                                                       int *ticket_next) {
   __shared__ WalkLfLds<Pix> S;
@@ -874,13 +874,14 @@ extern "C" int vp9hip_intra_islands_lf(vp9hip_ctx *ctx, const vp9hip_intra_task 
   memcpy(&th, h_thresh, sizeof(th));
   const FrameDev f = to_dev(frame);
   const int grid = sb_rows * planes + n_islands;
+  const txfm::Coefs cf = { d_coeffs, ctx->coeff16 };
   int *ticket = nullptr, *ticket_next = nullptr;
   rc = lf_tickets(ctx, &ticket, &ticket_next);
   if (rc) return rc;
 #define WALK_LF(PIX, SH)                                                                                              \
   hipLaunchKernelGGL((walk_lf_kernel<PIX, SH>), dim3(grid), dim3(256), 0, ctx->stream, d_lfm, sb_cols, sb_rows, planes, th, f, \
                      frame->aheight[0] / 8, ctx->lf_err_flag, gate_cur, gate_next, n_gate, d_sb_expected, d_tasks, d_islands, \
-                     d_wave_off, d_coeffs, (lf_granule *)ctx->lf_hand, gen, rp, ticket, ticket_next)
+                     d_wave_off, cf, (lf_granule *)ctx->lf_hand, gen, rp, ticket, ticket_next)
   if (!frame->hbd)
     WALK_LF(uint8_t, 0);
   else if (frame->bit_depth == 10)

@@ -27,6 +27,28 @@ __device__ __forceinline__ int coeff_rows(int eob, int tx_type, int n) {
   return n;
 }
 
+// The coefficient buffer of a launch: int32 slots (tran_low_t of the reference's build), or int16 ones when the
+// caller narrowed them (vp9hip_set_coeff_bits: a frame whose coefficients all fit travels at half the bytes).
+struct Coefs {
+  const void *p;
+  int c16;
+};
+struct CoefAt {
+  const void *p;
+  unsigned off;
+  int c16;
+  __device__ __forceinline__ int operator[](int i) const {
+    return c16 ? (int)((const short *)p)[off + (unsigned)i] : ((const int *)p)[off + (unsigned)i];
+  }
+};
+__device__ __forceinline__ CoefAt at(const Coefs &c, unsigned off) {
+  CoefAt a;
+  a.p = c.p;
+  a.off = off;
+  a.c16 = c.c16;
+  return a;
+}
+
 // round(16384 * cos(k*pi/64)), vpx_dsp/txfm_common.h:28-58
 #define CK(k) (txfm::kCos[k])
 __device__ constexpr int kCos[33] = { 16384, 16364, 16305, 16207, 16069, 15893, 15679, 15426, 15137,

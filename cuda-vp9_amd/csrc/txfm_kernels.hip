@@ -20,7 +20,7 @@ constexpr int TX_LDS_INTS = (256 / 32) * 32 * 33;  // the 32x32 class needs the 
 
 template <int N, typename Pix, bool HBD>
 __device__ __forceinline__ void idct_add_body(int *lds, int wg, const vp9hip_txb *__restrict__ blocks, int n_blocks,
-                                              const int32_t *__restrict__ coeffs, const FrameDev &f) {
+                                              const txfm::Coefs &coeffs, const FrameDev &f) {
   constexpr int BPW = 256 / N;          // blocks per workgroup
   constexpr int PITCH = N + 1;          // LDS row pitch in dwords
   static_assert(BPW * N * PITCH <= TX_LDS_INTS, "LDS budget");
@@ -38,7 +38,7 @@ __device__ __forceinline__ void idct_add_body(int *lds, int wg, const vp9hip_txb
   // vp9_idct.c:119-204: DCT_DCT (and every 32x32) takes the DC-only shortcut
   const bool dc_path = active && !lossless && (tx_type == 0 || N == 32) && (N == 4 ? eob <= 1 : eob == 1);
   const bool wht_dc = lossless && eob <= 1;
-  const int32_t *src = coeffs + (active ? blk.coeff_off : 0);
+  const txfm::CoefAt src = txfm::at(coeffs, active ? blk.coeff_off : 0);
 
   int v[N];
   if (active && !dc_path && !wht_dc) {
@@ -138,7 +138,7 @@ __device__ __forceinline__ int tx_xcd_order(int b, int s0, int s1) {
 
 template <typename Pix, bool HBD>
 __global__ __launch_bounds__(256) void idct_add_all_kernel(const vp9hip_txb *__restrict__ blocks, TxPlan plan,
-                                                           const int32_t *__restrict__ coeffs, FrameDev f) {
+                                                           txfm::Coefs coeffs, FrameDev f) {
   __shared__ int lds[TX_LDS_INTS];
   const int b = blockIdx.x;
   if (b < plan.wg_start[1])
@@ -174,12 +174,13 @@ extern "C" int vp9hip_idct_add_batch(vp9hip_ctx *ctx, const vp9hip_txb *d_blocks
   plan.wg_start[4] = acc_w;
   if (acc_w == 0) return VP9HIP_OK;
   const FrameDev f = to_dev(frame);
+  const txfm::Coefs cf = { d_coeffs, ctx->coeff16 };
   // the 32x32 class first in the grid would start the longest workgroups first, but the classes are
   // laid out 4x4 .. 32x32 like the record list; the grid is short enough (a few rounds) for this not to matter
   if (frame->hbd)
-    hipLaunchKernelGGL((idct_add_all_kernel<uint16_t, true>), dim3(acc_w), dim3(256), 0, ctx->stream, d_blocks, plan, d_coeffs, f);
+    hipLaunchKernelGGL((idct_add_all_kernel<uint16_t, true>), dim3(acc_w), dim3(256), 0, ctx->stream, d_blocks, plan, cf, f);
   else
-    hipLaunchKernelGGL((idct_add_all_kernel<uint8_t, false>), dim3(acc_w), dim3(256), 0, ctx->stream, d_blocks, plan, d_coeffs, f);
+    hipLaunchKernelGGL((idct_add_all_kernel<uint8_t, false>), dim3(acc_w), dim3(256), 0, ctx->stream, d_blocks, plan, cf, f);
   VP9HIP_CHECK(ctx, hipGetLastError());
   return VP9HIP_OK;
 }

@@ -59,6 +59,13 @@ extern "C" void vp9hip_destroy(vp9hip_ctx *ctx) {
 
 extern "C" const char *vp9hip_last_error(const vp9hip_ctx *ctx) { return ctx ? ctx->err : g_err; }
 
+extern "C" int vp9hip_set_coeff_bits(vp9hip_ctx *ctx, int bits) {
+  if (!ctx) return VP9HIP_EINVAL;
+  if (bits != 16 && bits != 32) VP9HIP_FAIL(ctx, VP9HIP_EINVAL, "vp9hip_set_coeff_bits: %d (16 or 32)", bits);
+  ctx->coeff16 = bits == 16;
+  return VP9HIP_OK;
+}
+
 extern "C" void *vp9hip_stream(vp9hip_ctx *ctx) { return ctx ? (void *)ctx->stream : NULL; }
 
 extern "C" int vp9hip_sync(vp9hip_ctx *ctx) {

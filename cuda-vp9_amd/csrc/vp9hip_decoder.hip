@@ -35,6 +35,7 @@ struct ListSet {
   size_t big_wave_cap;
   hipEvent_t uploaded, done;
   bool begun, have_coeffs, done_pending;
+  bool coeff16;  // the frame's coefficient slots are int16 (vp9hip_coeff_layout.narrow)
 };
 
 struct vp9hip_decoder {
@@ -333,12 +334,15 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
   int rc;
   // slots placed by the caller (block_off): where they go on the device does not depend on the packer, so the
   // coefficients — the bulk of a frame's bytes — start travelling before the lists are built
-  static const bool late_env = getenv("VP9HIP_LATE_COEFF_UPLOAD") != nullptr;  // measurement aid: upload after packing
-  const bool early = dqcoeff && layout->block_off && !late_env;
+  const bool early = dqcoeff && layout->block_off;
+  // int16 slots (vp9hip_coeff_layout.narrow): same offsets in coefficients, half the bytes on the way to the device
+  const bool narrow = dqcoeff && layout && layout->narrow != 0;
+  if (narrow && !layout->block_off) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: int16 slots need caller-placed slots (block_off)");
+  const size_t esz = narrow ? sizeof(int16_t) : sizeof(int32_t);
   if (early) {
     if (layout->total < 0 || layout->total > (int64_t)UINT32_MAX)
       DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: bad coefficient total");
-    if ((rc = dv_reserve(dec, &S->d_coeffs, sizeof(int32_t) * (size_t)(layout->total + 16)))) return rc;
+    if ((rc = dv_reserve(dec, &S->d_coeffs, esz * (size_t)(layout->total + 16)))) return rc;
     for (int64_t r = 0; r < layout->n_regions; ++r) {
       const vp9hip_coeff_region *g = &layout->regions[r];
       if (g->plane < 0 || g->plane > 2 || g->start < 0 || g->count < 0 ||
@@ -347,8 +351,9 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
         DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: coefficient region %lld out of range", (long long)r);
       }
       if (g->count)
-        DEC_HIP(dec, hipMemcpyAsync((int32_t *)S->d_coeffs.p + layout->plane_base[g->plane] + g->start, dqcoeff[g->plane] + g->start,
-                                    sizeof(int32_t) * (size_t)g->count, hipMemcpyHostToDevice, cs));
+        DEC_HIP(dec, hipMemcpyAsync((char *)S->d_coeffs.p + esz * (size_t)(layout->plane_base[g->plane] + g->start),
+                                    (const char *)dqcoeff[g->plane] + esz * (size_t)g->start, esz * (size_t)g->count,
+                                    hipMemcpyHostToDevice, cs));
     }
   }
   rc = vp9hip_pack_frame(S->pk, params, blocks, n_blocks, layout, &S->packed);
@@ -380,8 +385,9 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
   if (P->island_sb_expected &&
       (rc = dv_upload_on(dec, &S->d_sb_expected, P->island_sb_expected, sizeof(int32_t) * (size_t)P->sb_rows * P->sb_cols, cs)))
     return rc;
-  if (!early && (rc = dv_reserve(dec, &S->d_coeffs, sizeof(int32_t) * (size_t)(P->coeff_total + 16)))) return rc;
+  if (!early && (rc = dv_reserve(dec, &S->d_coeffs, esz * (size_t)(P->coeff_total + 16)))) return rc;
   S->have_coeffs = dqcoeff != NULL;
+  S->coeff16 = narrow;
   if (early) {
     if (P->coeff_total != layout->total) DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: coefficient total mismatch");
   } else if (dqcoeff && layout->block_off) {
@@ -391,8 +397,9 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
           layout->plane_base[g->plane] + g->start + g->count > P->coeff_total || !dqcoeff[g->plane])
         DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: coefficient region %lld out of range", (long long)r);
       if (g->count)
-        DEC_HIP(dec, hipMemcpyAsync((int32_t *)S->d_coeffs.p + layout->plane_base[g->plane] + g->start, dqcoeff[g->plane] + g->start,
-                                    sizeof(int32_t) * (size_t)g->count, hipMemcpyHostToDevice, cs));
+        DEC_HIP(dec, hipMemcpyAsync((char *)S->d_coeffs.p + esz * (size_t)(layout->plane_base[g->plane] + g->start),
+                                    (const char *)dqcoeff[g->plane] + esz * (size_t)g->start, esz * (size_t)g->count,
+                                    hipMemcpyHostToDevice, cs));
     }
   } else if (dqcoeff)
     for (int p = 0; p < 3; ++p)
@@ -523,6 +530,7 @@ extern "C" int vp9hip_decoder_run(vp9hip_decoder *dec, int phases, const int ref
   // dependency packet goes into the queue (every marker / barrier packet costs the command processor
   // microseconds between two kernels)
   if (hipEventQuery(S->uploaded) != hipSuccess) DEC_HIP(dec, hipStreamWaitEvent(st, S->uploaded, 0));
+  DEC_CTX(dec, vp9hip_set_coeff_bits(dec->ctx, (S->coeff16 && !dec->have_res) ? 16 : 32));
   if (!dec->timing_off) DEC_CTX(dec, vp9hip_timer_begin(dec->ctx, TIMER_RUN));
 
   const bool do_pred = (phases & (VP9HIP_PHASE_INTER | VP9HIP_PHASE_INTER_PRED)) != 0;

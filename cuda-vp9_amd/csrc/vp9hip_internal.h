@@ -17,6 +17,7 @@ struct vp9hip_ctx {
   void *scratch;
   size_t scratch_bytes;
   int cu_count;
+  int coeff16;  // the d_coeffs arrays of the launches hold int16 slots (vp9hip_set_coeff_bits)
   int *lf_err_flag;  // device flag (own allocation): a loop-filter wait timed out; set until vp9hip_sync reports it
   bool lf_err_armed; // a loop filter was launched since the flag was last read
   void *lf_hand;     // hand-off granules of the row-walking loop filter (lf_kernels.hip)

@@ -51,6 +51,11 @@ int vp9hip_create(int device, vp9hip_ctx **out);
 void vp9hip_destroy(vp9hip_ctx *ctx);
 const char *vp9hip_last_error(const vp9hip_ctx *ctx);
 int vp9hip_abi_version(void);
+/* Width of the slots of the d_coeffs arrays handed to the calls that follow (vp9hip_idct_add_batch, the intra calls):
+ * 32 (default) = int32, the reference build's tran_low_t; 16 = int16 — same offsets, half the bytes, for frames whose
+ * dequantised coefficients all fit (the bitstream front-end checks every one and falls back to 32, vp9hip_fe.h).
+ * The arithmetic is the same either way: a slot is sign-extended to the int the transforms start from. */
+int vp9hip_set_coeff_bits(vp9hip_ctx *ctx, int bits);
 /* hipStream_t of the context, as an opaque pointer (for event timing by the caller). */
 void *vp9hip_stream(vp9hip_ctx *ctx);
 int vp9hip_sync(vp9hip_ctx *ctx);

@@ -67,6 +67,13 @@ typedef struct vp9hip_fe_frame {
  * memory (vp9hip_decoder_host_alloc) lets them travel asynchronously.  threads: entropy threads (one tile column
  * each at most); <= 0: number of tile columns, capped at 16. */
 int vp9hip_fe_create(vp9hip_fe **out, vp9hip_alloc_fn alloc, vp9hip_free_fn release, void *user, int threads);
+/* Coefficient slots as int16 where a frame allows it (default: off, int32 slots as the reference's build keeps them).
+ * With on != 0 every frame is parsed into int16 slots (vp9hip_fe_frame.layout.narrow = 1: same offsets, half the bytes
+ * for the frame driver to move) while every coefficient is checked; a frame in which one does not fit is parsed again
+ * into int32 slots (layout.narrow = 0) — bit-exact either way.  vp9hip_fe_wide_frames: how often that happened.
+ * (on > 1, for tests: a coefficient of that magnitude or more already counts as not fitting.) */
+void vp9hip_fe_set_narrow_slots(vp9hip_fe *fe, int on);
+int vp9hip_fe_wide_frames(const vp9hip_fe *fe);
 void vp9hip_fe_destroy(vp9hip_fe *fe);
 const char *vp9hip_fe_error(const vp9hip_fe *fe);
 

@@ -111,7 +111,12 @@ typedef struct vp9hip_coeff_layout {
    * the reference's own clearing rule says can be non-zero (detoken_block, vp9_decodeframe.c:960-967) — and
    * nothing at eob 0; slots follow each other without gaps (oracle/patch_decodeframe.py E12).  0: every slot
    * has the full N*N coefficients, as the reference writes them. */
-  int32_t compact, reserved;
+  int32_t compact;
+  /* != 0 (needs block_off): the slots hold int16, not int32 — same offsets (in coefficients), half the bytes; the
+   * arrays are still passed as int32_t pointers.  For callers that have checked every coefficient of the frame
+   * (vp9hip_fe does; the reference's build keeps 32-bit coefficients, vpx_dsp/vpx_dsp_common.h:36-37, and its C
+   * transforms take them as such, so a frame with a single coefficient outside int16 keeps the wide slots). */
+  int32_t narrow;
 } vp9hip_coeff_layout;
 
 /* Rows of an N x N coefficient block (N = 4 << tx_size, row-major) that can hold non-zero values, by the rule

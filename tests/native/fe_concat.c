@@ -55,7 +55,8 @@ static uint64_t frame_sum(const vp9hip_fe_frame *fr) {
   }
   for (int64_t r = 0; r < fr->layout.n_regions; ++r) {
     const vp9hip_coeff_region *g = &fr->layout.regions[r];
-    h = fnv(h, fr->dqcoeff[g->plane] + g->start, sizeof(int32_t) * (size_t)g->count);
+    const size_t esz = fr->layout.narrow ? 2 : 4;
+    h = fnv(h, (const uint8_t *)fr->dqcoeff[g->plane] + esz * (size_t)g->start, esz * (size_t)g->count);
   }
   return h;
 }
@@ -71,7 +72,8 @@ static uint64_t frame_meaning(const vp9hip_fe_frame *fr) {
   h = fnv(h, fr->layout.block_off, sizeof(uint32_t) * 3 * (size_t)fr->n_blocks);
   for (int64_t r = 0; r < fr->layout.n_regions; ++r) {
     const vp9hip_coeff_region *g = &fr->layout.regions[r];
-    h = fnv(h, fr->dqcoeff[g->plane] + g->start, sizeof(int32_t) * (size_t)g->count);
+    const size_t esz = fr->layout.narrow ? 2 : 4;
+    h = fnv(h, (const uint8_t *)fr->dqcoeff[g->plane] + esz * (size_t)g->start, esz * (size_t)g->count);
   }
   vp9hip_packed out;
   if (vp9hip_pack_frame(g_pk, &fr->params, fr->blocks, fr->n_blocks, &fr->layout, &out)) return 0;

@@ -38,8 +38,9 @@ def check(d, name, *opts):
                                   "s352_12", "s352_tr", "s352_svc2", "s704_svc3"])
 def test_standalone_decoder_md5(name):
     assert os.path.exists(DEC), "cuda-vp9_amd/vp9hip_dec not built (make -C cuda-vp9_amd)"
-    check(SMALL, name)
+    check(SMALL, name)  # (int16 coefficient slots wherever a frame's coefficients fit: the default)
     check(SMALL, name, "--serial", "--threads=1")
+    check(SMALL, name, "--wide-slots")  # int32 slots throughout, the reference's width
 
 
 @pytest.mark.parametrize("name", ["S-1440", "S-1440-q44", "S-2160", "S-2176", "S-1080-10", "S-1440-10", "S-1080-8"])
