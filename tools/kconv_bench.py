@@ -59,7 +59,9 @@ for (W, H) in ((2560, 1440), (3840, 2160), (3840, 2160 * 8)):
                 ctx.sync()
                 ms = sorted(ctx.timer_read(i) for i in range(N))[N // 2]
                 bps = 2 if bd > 8 else 1
-                px = (tasks["w"].astype(np.int64) * tasks["h"]).sum()
+                # samples inside the frame (a block of the bottom row overhangs it: the kernels clip)
+                vis = np.minimum(tasks["h"].astype(np.int64), np.where(tasks["plane"] > 0, H >> 1, H) - tasks["dst_y"])
+                px = (tasks["w"].astype(np.int64) * vis).sum()
                 byts = px * bps * (2 + compound) + 32 * len(tasks)
                 gbs = byts / (ms * 1e-3) / 1e9
                 rec = dict(frame=f"{W}x{H}", bd=bd, block=bs, compound=compound, tasks=int(len(tasks)), ms=round(ms, 4),

@@ -65,7 +65,9 @@ for (W, H) in ((3840, 2160),):
                 ctx.timer_end(0); ctx.sync()
                 print("back-to-back per launch us", ctx.timer_read(0) / 50 * 1e3, "single-event us", ms * 1e3)
                 bps = 2 if bd > 8 else 1
-                px = (tasks["w"].astype(np.int64) * tasks["h"]).sum()
+                # samples inside the frame (a block of the bottom row overhangs it: the kernels clip)
+                vis = np.minimum(tasks["h"].astype(np.int64), np.where(tasks["plane"] > 0, H >> 1, H) - tasks["dst_y"])
+                px = (tasks["w"].astype(np.int64) * vis).sum()
                 byts = px * bps * (2 + compound) + 32 * len(tasks)
                 gbs = byts / (ms * 1e-3) / 1e9
                 rec = dict(frame=f"{W}x{H}", bd=bd, block=bs, compound=compound, tasks=int(len(tasks)), ms=round(ms, 4),

@@ -27,7 +27,7 @@ def source_hash(files):
             h.update(fh.read())
     return h.hexdigest()[:16]
 
-FAMILY = (("inter_fast_kernel", "convolve"), ("inter_fast16_kernel", "convolve"), ("inter_reg_kernel", "convolve"), ("inter_pred_kernel", "convolve_generic"), ("idct_add", "idct_add"),
+FAMILY = (("inter_fast_kernel", "convolve"), ("inter_fast16_kernel", "convolve"), ("inter_reg_kernel", "convolve"), ("inter_reg16_kernel", "convolve"), ("inter_pred_kernel", "convolve_generic"), ("idct_add", "idct_add"),
           ("walk_lf_kernel", "walk_lf"), ("intra_island_kernel", "intra"), ("intra_residual_kernel", "intra_residual"), ("intra_wave_kernel", "intra_waves"), ("lf_rows", "loop_filter"),
           ("lf_diag", "loop_filter_diag"), ("residual_", "residual"))
 
