@@ -395,18 +395,13 @@ static void counting_sort(const void *src, void *dst, size_t rec, const int32_t 
  * of the walk; measured).  In front of that: the group g = max(first superblock row - 1, 0) —
  * filter row r is placed behind the islands of groups <= r in the fused launch's grid, which are all the islands
  * that touch superblock rows <= r + 1, i.e. all it ever waits for. */
-static int g_isl_w[3] = { 56, 60, 0 };
 static int island_group(const vp9hip_intra_island *x) {
   const int r = (int)(x->reserved & 255);
   return r > 0 ? r - 1 : 0;
 }
 static int island_key(const vp9hip_intra_island *x) {
-  int r = (int)(x->reserved & 255), c = (int)((x->reserved >> 16) & 255);
-  if (g_isl_w[2]) {
-    r = r > 0 ? r - 1 : 0;
-    c = c > 0 ? c - 1 : 0;
-  }
-  return g_isl_w[0] * (r + c) - g_isl_w[1] * (int)x->n_waves;
+  const int r = (int)(x->reserved & 255), c = (int)((x->reserved >> 16) & 255);
+  return 56 * (r + c) - 60 * (int)x->n_waves;
 }
 static int island_deadline_first(const void *a, const void *b) {
   const vp9hip_intra_island *x = (const vp9hip_intra_island *)a, *y = (const vp9hip_intra_island *)b;
@@ -1337,10 +1332,6 @@ int vp9hip_pack_frame(vp9hip_packer *pk, const vp9hip_frame_params *P, const vp9
           }
         }
         a = e;
-      }
-      {
-        const char *e = getenv("VP9HIP_ISLAND_W");
-        if (e) sscanf(e, "%d,%d,%d", &g_isl_w[0], &g_isl_w[1], &g_isl_w[2]);
       }
       qsort(is, (size_t)n_is, sizeof(*is), island_deadline_first);
       if (vec_reserve(&pk->row_pos, sizeof(int32_t) * (size_t)(sb_rows + 1))) PK_FAIL(pk, VP9HIP_ENOMEM, "vp9hip_pack_frame: out of memory");

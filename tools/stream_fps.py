@@ -12,7 +12,7 @@ import bench  # noqa: E402
 
 def main():
     out = {}
-    for s in ("S-1440", "S-1440-q44", "S-1080-10", "S-2160", "S-2176"):
+    for s in ("S-1440", "S-1440-q44", "S-1440-10", "S-1080-8", "S-1080-10", "S-2160", "S-2176"):
         ivf = os.path.join(ROOT, "tests", "streams_big", s + ".ivf")
         if not os.path.exists(ivf):
             continue
