@@ -308,16 +308,32 @@ __device__ __forceinline__ void lf_pass_h(Pix *tile, const unsigned *ctl, int x0
 // co-resident (69 at 1440p), and row r only ever waits on row r-1, so there is no cycle.
 // The left 8 columns of a tile never leave LDS between two superblocks of a row.
 // Every wait is bounded all the same: a row that gives up raises the context's error flag (vp9hip_sync reports it).
-constexpr int LF_SPIN_LIMIT = 1 << 18;  // x (s_sleep + L2 round trip) ~ a fraction of a second, then give up
+// The bound is TIME (the 100 MHz constant clock, looked at every 1024 polls), and a wait for another ROW gets twice
+// the time of a wait for islands or for the workgroup's own waves: when something upstream stalls, the wait at the
+// root of the chain gives up first and is the one the error record names.
+constexpr long long LF_WAIT_TICKS = 30 * 1000 * 1000;  // 0.3 s
+struct LfWaitClock {
+  int polls = 0;
+  long long t0 = 0;
+  __device__ __forceinline__ bool expired(long long limit) {
+    if ((++polls & 1023) != 0) return false;
+    const long long now = (long long)wall_clock64();
+    if (t0 == 0) t0 = now;
+    return now - t0 > limit;
+  }
+};
 
-// err[0]: bit 0 a filter row gave up waiting, bit 1 an island did not fit; err[1..3]: what the FIRST wait that gave
+// err[0]: bit 0 a filter row gave up waiting, bit 1 an island did not fit; err[4], err[5]: the launch's ticket counter
+// at that moment and its grid size; err[1..3]: what the FIRST wait that gave
 // up was waiting for — kind (1 island counter, 2 rows of the row above, 3 the workgroup's own filtering wave) |
 // plane << 8 | row << 16, superblock column, and the value it saw.  vp9hip_sync puts them into the error text.
-__device__ __forceinline__ void lf_give_up(int *err, int kind, int pl, int sr, int col, int seen) {
+__device__ __forceinline__ void lf_give_up(int *err, int kind, int pl, int sr, int col, int seen, const int *ticket) {
   if (atomicOr(err, 1) == 0) {
     err[1] = kind | (pl << 8) | (sr << 16);
     err[2] = col;
     err[3] = seen;
+    err[4] = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // workgroups that have started
+    err[5] = (int)gridDim.x;
   }
 }
 
@@ -362,7 +378,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
                                              int sb_cols, int sr, int pl, const LfThreshDev &th, const FrameDev &f,
                                              int mi_rows, int *err, volatile unsigned *flags,
                                              const int *gate_done, const int *gate_expected, int sb_rows,
-                                             lf_granule *hand_base, unsigned gen) {
+                                             lf_granule *hand_base, unsigned gen, const int *ticket) {
   constexpr int TP = TileCfg<Pix>::TP;
   constexpr int PPD = 4 / sizeof(Pix);
   constexpr int n = N;
@@ -424,12 +440,12 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
     if (gate_done == nullptr || col >= sb_cols) return;
     for (int r = sr; r <= sr + 1 && r < sb_rows; ++r) {
       const int need = gate_expected[r * sb_cols + col];
-      int spins = 0;
+      LfWaitClock clk;
       while (!dead && __hip_atomic_load(&gate_done[r * sb_cols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > LF_SPIN_LIMIT) {
+        if (clk.expired(LF_WAIT_TICKS)) {
           if (lane == 0)
-            lf_give_up(err, 1, pl, r, col, __hip_atomic_load(&gate_done[r * sb_cols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (need << 16));
+            lf_give_up(err, 1, pl, r, col, __hip_atomic_load(&gate_done[r * sb_cols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (need << 16), ticket);
           dead = true;
         }
       }
@@ -446,9 +462,10 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       // the row above published them as tagged granules — columns 0..55 of this superblock after its horizontal
       // pass of superblock sc, the last 8 after the first position of its vertical pass of sc+1: poll until every
       // granule this wave needs carries this launch's tag
-      int spins = 0;
+      LfWaitClock clk;
       for (;;) {
         bool ok = true;
+        int have = 0;
 #pragma unroll
         for (int k = 0; k < KA; ++k) {
           const int i = lane + 64 * k;
@@ -458,12 +475,13 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
             const lf_granule g = ld_granule(&hand[(size_t)((sr - 1) * 8 + r) * hpitch + gx / PPD]);
             above[k] = (unsigned)g;
             ok = ok && (unsigned)(g >> 32) == gen;
+            have += (unsigned)(g >> 32) == gen;
           }
         }
         if (__builtin_amdgcn_ballot_w64(!ok) == 0 || dead) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > LF_SPIN_LIMIT) {
-          if (lane == 0) lf_give_up(err, 2, pl, sr, sc, 0);
+        if (clk.expired(2 * LF_WAIT_TICKS)) {  // (lane 0 holds the leftmost granules: columns 0.. of the first row)
+          if (lane == 0) lf_give_up(err, 2, pl, sr, sc, have | (KA << 16), ticket);
           dead = true;
         }
       }
@@ -577,10 +595,10 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       if (sc > 0) {
         handoff((const unsigned *)(tiles + ((sc - 1) & 1) * TILE), x0 - n, 8, n);
       }
-      for (int spins = 0; flags[0] < (unsigned)(sc + 1); ++spins) {  // wave 0 of this workgroup: bounded all the same
+      for (LfWaitClock clk; flags[0] < (unsigned)(sc + 1);) {  // wave 0 of this workgroup: bounded all the same
         __builtin_amdgcn_s_sleep(1);
-        if (spins > LF_SPIN_LIMIT) {
-          if (lane == 0) lf_give_up(err, 3, pl, sr, sc, (int)flags[0]);
+        if (clk.expired(LF_WAIT_TICKS)) {
+          if (lane == 0) lf_give_up(err, 3, pl, sr, sc, (int)flags[0], ticket);
           break;
         }
       }
@@ -627,13 +645,13 @@ template <typename Pix, int SH>
 __device__ __forceinline__ void lf_row_entry(LfRowLds<Pix> &L, const vp9hip_lfm *__restrict__ lfms, int sb_cols, int sb_rows,
                                              const LfThreshDev &th, const FrameDev &f, int mi_rows, int *err,
                                              const int *gate_done, const int *gate_expected, lf_granule *hand, unsigned gen,
-                                             int sr, int pl) {
+                                             int sr, int pl, const int *ticket) {
   if (pl == 0 || f.awidth[pl] == f.awidth[0])
     lf_row2_body<Pix, 64, SH>(L.tiles, L.ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, err, L.flags, gate_done, gate_expected,
-                              sb_rows, hand, gen);
+                              sb_rows, hand, gen, ticket);
   else
     lf_row2_body<Pix, 32, SH>(L.tiles, L.ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, err, L.flags, gate_done, gate_expected,
-                              sb_rows, hand, gen);
+                              sb_rows, hand, gen, ticket);
 }
 
 // Forward progress.  A workgroup's place in the launch's ORDER is not its hardware index but a ticket it draws when it
@@ -666,7 +684,7 @@ __global__ __launch_bounds__(256) void lf_rows2_kernel(const vp9hip_lfm *__restr
   __shared__ LfRowLds<Pix> L;
   const int b = draw_ticket(ticket, ticket_next);
   const int sr = b / planes, pl = b % planes;
-  lf_row_entry<Pix, SH>(L, lfms, sb_cols, sb_rows, th, f, mi_rows, err, nullptr, nullptr, hand, gen, sr, pl);
+  lf_row_entry<Pix, SH>(L, lfms, sb_cols, sb_rows, th, f, mi_rows, err, nullptr, nullptr, hand, gen, sr, pl, ticket);
 }
 
 // Where the filter's rows sit among the islands in the fused launch's grid: the `planes` workgroups of row r
@@ -717,7 +735,7 @@ __global__ __launch_bounds__(256, WALK_LF_WAVES) void walk_lf_kernel(const vp9hi
     if (sr == 0 && pl == 0)  // (write-through stores at agent scope, like every other access to the counters)
       for (int i = (int)threadIdx.x; i < n_gate; i += 256) __hip_atomic_store(&gate_next[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     VP9HIP_STAMP(0);
-    lf_row_entry<Pix, SH>(S.row, lfms, sb_cols, sb_rows, th, f, mi_rows, err, gate_done, gate_expected, hand, gen, sr, pl);
+    lf_row_entry<Pix, SH>(S.row, lfms, sb_cols, sb_rows, th, f, mi_rows, err, gate_done, gate_expected, hand, gen, sr, pl, ticket);
     VP9HIP_STAMP(7);
     return;
   }
@@ -754,7 +772,8 @@ static int lf_handoff_buffer(vp9hip_ctx *ctx, const vp9hip_frame *frame, int sb_
       VP9HIP_CHECK(ctx, hipMalloc(&ctx->lf_hand, need + need / 4));
       ctx->lf_hand_bytes = need + need / 4;
     }
-    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_hand, 0, ctx->lf_hand_bytes));
+    VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->lf_hand, 0, ctx->lf_hand_bytes, ctx->stream));  // (in the launch's own stream: the
+    // context's stream does not synchronise with the null stream, and a fill that lands late wipes granules)
     ctx->lf_gen = 0;
   }
   *gen = ++ctx->lf_gen;
@@ -766,7 +785,7 @@ static int lf_tickets(vp9hip_ctx *ctx, int **cur, int **nxt) {
   constexpr int LINE = 64;  // ints: 256 bytes apart
   if (!ctx->lf_ticket) {
     VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_ticket, 2 * LINE * sizeof(int)));
-    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_ticket, 0, 2 * LINE * sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->lf_ticket, 0, 2 * LINE * sizeof(int), ctx->stream));
     ctx->lf_ticket_parity = 0;
   }
   *cur = ctx->lf_ticket + ctx->lf_ticket_parity * LINE;
@@ -790,8 +809,8 @@ static int lf_prepare(vp9hip_ctx *ctx, const char *who, const vp9hip_lfm *d_lfm,
   // the error flag lives in an allocation of its own: it stays set until vp9hip_sync has reported it, however
   // many frames are enqueued behind the one that gave up
   if (!ctx->lf_err_flag) {
-    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_err_flag, 4 * sizeof(int)));
-    VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, 4 * sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMalloc((void **)&ctx->lf_err_flag, 8 * sizeof(int)));
+    VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->lf_err_flag, 0, 8 * sizeof(int), ctx->stream));
   }
   ctx->lf_err_armed = true;
   return lf_handoff_buffer(ctx, frame, sb_rows, gen);

@@ -72,11 +72,12 @@ extern "C" int vp9hip_sync(vp9hip_ctx *ctx) {
   if (!ctx) return VP9HIP_EINVAL;
   VP9HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->lf_err_flag && ctx->lf_err_armed) {
-    int flag[4] = { 0, 0, 0, 0 };
+    int flag[8] = { 0 };
     VP9HIP_CHECK(ctx, hipMemcpy(flag, ctx->lf_err_flag, sizeof(flag), hipMemcpyDeviceToHost));
     ctx->lf_err_armed = false;
     if (flag[0]) {
-      VP9HIP_CHECK(ctx, hipMemset(ctx->lf_err_flag, 0, sizeof(flag)));  // reported once
+      VP9HIP_CHECK(ctx, hipMemsetAsync(ctx->lf_err_flag, 0, sizeof(flag), ctx->stream));  // reported once
+      VP9HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
       if (flag[0] & 2)
         VP9HIP_FAIL(ctx, VP9HIP_EINVAL,
                     "vp9hip_intra_islands_lf: an island does not fit the LDS window (VP9HIP_ISLAND_FITS); the frames "
@@ -85,8 +86,9 @@ extern "C" int vp9hip_sync(vp9hip_ctx *ctx) {
                                            "its own filtering wave" };
       VP9HIP_FAIL(ctx, VP9HIP_EDEVICE,
                   "loop filter: a superblock row gave up waiting (for the row above or for the intra islands around it): plane %d row %d "
-                  "at superblock column %d waited for %s (saw %d of %d); the frames enqueued since the last synchronisation are not valid",
-                  (flag[1] >> 8) & 255, flag[1] >> 16, flag[2], what[flag[1] & 3], flag[3] & 0xffff, flag[3] >> 16);
+                  "at superblock column %d waited for %s (had %d of %d; %d of the launch's %d workgroups had started); the frames enqueued "
+                  "since the last synchronisation are not valid",
+                  (flag[1] >> 8) & 255, flag[1] >> 16, flag[2], what[flag[1] & 3], flag[3] & 0xffff, flag[3] >> 16, flag[4], flag[5]);
     }
   }
   return VP9HIP_OK;

@@ -95,8 +95,14 @@ def test_loop_filter_gives_up_cleanly_when_an_island_never_reports(hip, oracle):
     bad[len(bad) // 2] += 1
     good_buf, job.d_sb_expected = job.d_sb_expected, ctx.alloc(bad)
     job.run()
-    with pytest.raises(hip.Vp9HipError, match="gave up waiting"):
+    # ... and name the wait at the ROOT of the chain (rows below the stalled one wait for rows, with twice the time):
+    # the islands of that superblock, one mark short, every workgroup of the launch started
+    with pytest.raises(hip.Vp9HipError, match="gave up waiting") as ei:
         ctx.sync()
+    import re
+    m = re.search(r"waited for the intra islands of a superblock \(had (\d+) of (\d+); (\d+) of the launch's (\d+) workgroups", str(ei.value))
+    assert m, str(ei.value)
+    assert int(m.group(1)) + 1 == int(m.group(2)) == int(bad[len(bad) // 2]) and m.group(3) == m.group(4), str(ei.value)
     ctx.sync()  # reported once
     job.d_sb_expected.free()
     job.d_sb_expected = good_buf

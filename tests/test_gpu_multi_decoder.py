@@ -8,6 +8,7 @@ else is in flight on the GPU — other contexts of the process, other processes 
  * test_decoders_in_one_process: N decoders, one host thread each, dense frames with a VP9 partition (blockgen),
    many frames in flight per decoder; every decoder's last frame bit-equal to the reference's own C functions
    (oracle/_ref through refframe), vp9hip_sync reports no row that gave up.
+ * test_first_launch_of_a_context_on_a_busy_gpu: decoders created and destroyed beside two busy ones.
  * test_decoder_processes_side_by_side: N vp9hip_dec processes on the same stream side by side, every loop's MD5
    lines equal to the golden list (what tools/multi_process_check.sh ran by hand in round 2)."""
 import ctypes
@@ -87,6 +88,72 @@ def test_decoders_in_one_process(hip, W, H, bd, n_dec, rounds):
         got = [np.zeros((dd[1], dd[0]), dt) for dd in dims]
         d.download(3, got, W, H, bd)
         assert refframe.frame_md5(got, W, H) == want[s % 2], f"decoder {s}"
+        d.close()
+
+
+def test_first_launch_of_a_context_on_a_busy_gpu(hip):
+    """A context's FIRST fused launch sets up its hand-off granules, ticket counters and error record.  Those fills
+    must be ordered with the launch (they go into the context's own stream): the streams do not synchronise with the
+    null stream, and a fill that landed after the launch had started — which takes a busy GPU, i.e. other decoders —
+    wiped granules a row below was waiting for ("gave up waiting for the rows handed down by the row above", seen
+    once in round 3's full run).  Two decoders keep the GPU busy; fresh decoders come and go beside them."""
+    import refframe
+    import workload
+    W, H, bd = 1280, 720, 8
+    rng = np.random.default_rng(5)
+    dims, _ = refframe.plane_dims(W, H)
+    refs = [[np.ascontiguousarray(workload.smooth_noise(rng, d[1], d[0], bd, sigma=1.5 + k).astype(np.uint8)) for d in dims]
+            for k in range(3)]
+    blocks = blockgen.gen_blocks(rng, W, H, hip.BLOCK_DTYPE, intra_frac=0.08, skip_frac=0.35)
+    coef, eob = blockgen.gen_coeffs(rng, blocks, W, H, bd)
+    P = _params(hip, W, H, bd)
+    th = hip.LfThresh()
+    hip.lib().vp9hip_lf_frame_init(32, 0, None, None, 0, 0, None, None, None, ctypes.byref(th))
+    ALL = hip.PHASE_INTER | hip.PHASE_INTRA | hip.PHASE_LF
+    rf = refframe.RefFrame(refframe.load_ref(), blocks, W, H, bd, refs, [(W, H)] * 3, coef, eob, tiles=2)
+    rf.run()
+    want = refframe.frame_md5(rf.planes(), W, H)
+
+    def fresh():
+        d = hip.Decoder(0)
+        for k in range(3):
+            d.upload(k, refs[k], W, H, bd)
+        d.alloc_slot(3, W, H, bd)
+        d.begin_frame(P, blocks, eob, coef)
+        d.set_timing(False)
+        return d
+
+    stop = threading.Event()
+    failures = []
+
+    def busy(d):
+        try:
+            while not stop.is_set():
+                for _ in range(20):
+                    d.run(ALL, (0, 1, 2), 3, thresh=th)
+                d.sync()
+        except Exception as e:  # noqa: BLE001
+            failures.append(str(e))
+
+    background = [fresh() for _ in range(2)]
+    thr = [threading.Thread(target=busy, args=(d,)) for d in background]
+    for x in thr:
+        x.start()
+    try:
+        for k in range(12):
+            d = fresh()
+            d.run(ALL, (0, 1, 2), 3, thresh=th)  # first launch of this context
+            d.sync()
+            got = [np.zeros((dd[1], dd[0]), np.uint8) for dd in dims]
+            d.download(3, got, W, H, bd)
+            assert refframe.frame_md5(got, W, H) == want, f"fresh decoder {k}"
+            d.close()
+    finally:
+        stop.set()
+        for x in thr:
+            x.join()
+    assert not failures, failures[0]
+    for d in background:
         d.close()
 
 
