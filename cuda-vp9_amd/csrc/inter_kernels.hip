@@ -253,6 +253,24 @@ __device__ __forceinline__ void transpose4(unsigned a, unsigned b, unsigned c, u
 __device__ const unsigned kEdgeSel[7] = { 0x00000000u, 0x01000000u, 0x02010000u, 0x03020100u,
                                           0x03030201u, 0x03030302u, 0x03030303u };
 
+// Probe builds (-DVP9HIP_STAMPS, tools/ only): per wave, the 100 MHz clock at entry and exit and the shader clock at the
+// stages of inter_reg_body (window loads issued / arrived / rows done / columns done / stores issued)
+#ifdef VP9HIP_STAMPS
+__device__ long long g_conv_stamps[8 * 16384];
+#define CONV_STAMP(k, v)                                                                                  \
+  do {                                                                                                    \
+    const int w_ = (int)blockIdx.x * (REG_THREADS / 64) + (int)(threadIdx.x >> 6);                        \
+    if ((threadIdx.x & 63) == 0 && w_ < 16384) g_conv_stamps[w_ * 8 + (k)] = (long long)(v);             \
+  } while (0)
+#define CONV_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+extern "C" int vp9hip_debug_conv_stamps(long long *out, int n_waves) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), sizeof(long long) * 8 * (size_t)n_waves) == hipSuccess ? 0 : -1;
+}
+#else
+#define CONV_STAMP(k, v) do { } while (0)
+#define CONV_DRAIN() do { } while (0)
+#endif
+
 template <int W, int H>
 __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *__restrict__ tasks, int n_tasks,
                                                const RefTable &refs, const FrameDev &dstf,
@@ -263,6 +281,8 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
   const int strip = gl / C::L, j = gl % C::L;
   const int ti = strip / C::SPT, sub = strip % C::SPT;
   const bool active = ti < n_tasks;
+  CONV_STAMP(0, wall_clock64());
+  CONV_STAMP(1, clock64());
   vp9hip_inter_task t;
   if (active) t = tasks[ti];
   const int plane = active ? t.plane : 0;
@@ -316,6 +336,11 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
           }
         }
       }
+      if (r == 0) {
+        CONV_STAMP(2, clock64());  // window loads issued (the task record has arrived)
+        CONV_DRAIN();
+        CONV_STAMP(3, clock64());  // window arrived
+      }
       // rows
       unsigned hr[4 * NG];
       {
@@ -328,6 +353,7 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
 #pragma unroll
         for (int i = NR; i < 4 * NG; ++i) hr[i] = 0;
       }
+      if (r == 0) CONV_STAMP(4, clock64());  // rows done
       // columns
       unsigned col[4][NG];
 #pragma unroll
@@ -355,8 +381,11 @@ __device__ __forceinline__ void inter_reg_body(int wg, const vp9hip_inter_task *
         k[y] = o;
         if (!first && y < vis_h) *(unsigned *)(dst + (size_t)y * dstride) = res;
       }
+      if (r == 0) CONV_STAMP(5, clock64());  // first reference done, stores issued
     }
   }
+  CONV_STAMP(6, clock64());
+  CONV_STAMP(7, wall_clock64());
 }
 
 // The thirteen shapes of vp9hip_inter_class in one launch: workgroups [wg_start[k], wg_start[k+1]) serve shape k.
@@ -429,6 +458,8 @@ __device__ __forceinline__ void inter_reg16_body(int wg, const vp9hip_inter_task
   const int strip = gl / C::L, j = gl % C::L;
   const int ti = strip / C::SPT, sub = strip % C::SPT;
   const bool active = ti < n_tasks;
+  CONV_STAMP(0, wall_clock64());
+  CONV_STAMP(1, clock64());
   vp9hip_inter_task t;
   if (active) t = tasks[ti];
   const int plane = active ? t.plane : 0;
