@@ -37,6 +37,9 @@ import subprocess
 import sys
 import time
 
+# (before anything initialises the HIP runtime: see cuda-vp9_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -568,7 +571,8 @@ def main():
             barrier()
             barriers = 2
             tm = time.perf_counter() - tm0
-            multi = {"streams": args.streams, "frames": n_rounds * args.streams, "frames_per_s": round(n_rounds * args.streams / tm, 1)}
+            multi = {"streams": args.streams, "frames": n_rounds * args.streams, "frames_per_s": round(n_rounds * args.streams / tm, 1),
+                     "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
             if failures:
                 multi = {"error": failures[0]}
             for d in decs:

@@ -17,6 +17,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvp9hip.so")
 
+# Several decoders in one process: every decoder has its own streams, and the ROCm runtime multiplexes a process's streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4) — kernels of two decoders that share a queue run one after the
+# other.  Eight queues let eight decoders' launches overlap (tools/multi_stream_probe.py: 8 decoders 5.0 k -> 7.3 k
+# frames/s).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the process; a value the
+# caller has set is kept.  (C hosts: export it before the process starts)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _lib = None
 
 

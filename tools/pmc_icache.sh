@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_icache
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVE_CYCLES SQ_IFETCH --output-format csv -d $OUT/ic -o ic -- python3 $ROOT/tools/profile_phase.py --phase all --steps 6 --no-overlap > $OUT/ic.log 2>&1
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVE_CYCLES SQ_IFETCH --output-format csv -d $OUT/ic -o ic -- python3 $ROOT/tools/profile_phase.py --separate --steps 6 > $OUT/ic.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 per = collections.defaultdict(lambda: collections.defaultdict(list))
