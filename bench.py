@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo with --dry-run on CPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="host side only (launcher, stream sharding, C packer, stats reduce): no GPU is touched")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="rehearsal of --gpus N on a box with ONE GPU: every rank uses GPU 0, the stats reduce runs on gloo "
+                         "(RCCL refuses two ranks on one device); the line says so under config")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -83,7 +86,7 @@ def launch_ranks(args):
     if not args.dry_run:
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not (args.ranks_share_gpu and have >= 1):
             print(json.dumps({"error": f"--gpus {args.gpus} asked for, {have} GPU(s) visible", "n_gpus": args.gpus}))
             return 2
     with socket.socket() as s:
@@ -357,17 +360,22 @@ def main():
         os.environ["VP9HIP_PACK_THREADS"] = str(placement["pack_threads"])
 
     dist = None
+    gpu = 0 if args.ranks_share_gpu else local_rank  # device index of this rank
+    if args.ranks_share_gpu:
+        args.backend = "gloo"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dry_run:
+        if args.dry_run or args.ranks_share_gpu:
+            if not args.dry_run:
+                torch.cuda.set_device(gpu)
             dist.init_process_group(backend=args.backend)
         else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank))
+            torch.cuda.set_device(gpu)
+            dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", gpu))
     elif not args.dry_run:
-        torch.cuda.set_device(local_rank)
-    dev = None if args.dry_run else torch.device("cuda", local_rank)
+        torch.cuda.set_device(gpu)
+    dev = None if (args.dry_run or args.ranks_share_gpu) else torch.device("cuda", gpu)  # where the stats reduce runs
 
     W, H, bd = args.width, args.height, args.bit_depth
     n_frames = max(1, min(args.frames, 4))
@@ -405,7 +413,7 @@ def main():
         return 0
 
     ALL = hip.PHASE_INTER | hip.PHASE_INTRA | hip.PHASE_LF
-    dec = hip.Decoder(local_rank)
+    dec = hip.Decoder(gpu)
     for k in range(3):
         dec.upload(k, refs[k], W, H, bd)
     dec.alloc_slot(3, W, H, bd)
@@ -536,7 +544,7 @@ def main():
         try:  # a secondary figure: whatever happens in it, the line with `value` is printed
             decs = []
             for s in range(args.streams):
-                d = hip.Decoder(local_rank)
+                d = hip.Decoder(gpu)
                 for k in range(3):
                     d.upload(k, refs[k], W, H, bd)
                 d.alloc_slot(3, W, H, bd)
@@ -590,7 +598,7 @@ def main():
         fps_mine, frames_mine = 0.0, 0
         if have_own:
             try:  # whatever happens here, every rank reaches the collective below
-                runs = run_own_dec(ivf_big, loops=5, device=local_rank, timeout=300, threads=placement["entropy_threads"] if placement else None)
+                runs = run_own_dec(ivf_big, loops=5, device=gpu, timeout=300, threads=placement["entropy_threads"] if placement else None)
                 warm = runs[1:] or runs
                 if warm:
                     fps_mine, frames_mine = sum(f for _, f in warm) / len(warm), warm[0][0]
@@ -648,7 +656,7 @@ def main():
                                    f"{len(lists0['intra_decode_order'])} intra tx blocks in {lists0['n_waves']} waves, "
                                    f"{lists0['sb_rows']}x{lists0['sb_cols']} SBs) packed by vp9hip_pack_frame, run by "
                                    f"vp9hip_decoder_run; {n_frames} distinct frames resident in HBM, one stream per GPU",
-                       "parallelism": f"streams{world}"},
+                       "parallelism": f"streams{world}" + (" (rehearsal: all ranks on GPU 0, gloo)" if args.ranks_share_gpu else "")},
             "md5_match_vs_reference_c": md5_match,
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_baseline,
             "pack_upload_run": {"frames_per_s": round(pipe_total / t_pipe_max, 1), "frames": n_pipe,
