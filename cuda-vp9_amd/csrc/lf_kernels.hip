@@ -571,6 +571,17 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
   if (threadIdx.x == 0) flags[0] = 0;
   __syncthreads();
   VP9HIP_STAMP(1);
+#ifdef VP9HIP_STAMPS  // probe builds: where the filtering wave's steps go (sums over the row, 100 MHz ticks)
+  long long acc_[4] = { 0, 0, 0, 0 }, tm_ = wall_clock64();
+#define LF_ACC(k)                          \
+  do {                                     \
+    const long long n_ = wall_clock64();   \
+    acc_[k] += n_ - tm_;                   \
+    tm_ = n_;                              \
+  } while (0)
+#else
+#define LF_ACC(k) do { } while (0)
+#endif
   for (int sc = 0; sc < ncols; ++sc) {
     const int x0 = sc * n;
     const bool last = sc == ncols - 1;
@@ -606,7 +617,9 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       if (sc > 0) handoff(t32, x0, 0, 8);
       if (sc > 0) bulk_writeback(sc - 1, 1);
     }
+    LF_ACC(0);
     __syncthreads();
+    LF_ACC(1);
     // ---- phase B + C: wave 0 filters and moves the strip, wave 1 prefetches, wave 2 publishes
     if (wave == 0) {
       lf_pass_h<Pix, N>(tile, ctl, x0, pw, mrows, sh);
@@ -624,8 +637,15 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
         store_interior(sc + 1);
       }
     }
+    LF_ACC(2);
     __syncthreads();
+    LF_ACC(3);
   }
+#ifdef VP9HIP_STAMPS
+  if (threadIdx.x == 0 && s_stamp_slot < 4096)
+    for (int k = 0; k < 4; ++k) g_stamps[s_stamp_slot * 8 + 2 + k] = acc_[k];
+  if (threadIdx.x == 64 && s_stamp_slot < 4096) g_stamps[s_stamp_slot * 8 + 6] = acc_[2];  // wave 1's own phase B work
+#endif
   if (wave == 2) {  // the last superblock's bottom rows, right strip included
     handoff((const unsigned *)(tiles + ((ncols - 1) & 1) * TILE), (ncols - 1) * n, 8, n + 8);
     bulk_writeback(ncols - 1, 1);

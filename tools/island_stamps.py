@@ -35,7 +35,7 @@ th = hip.LfThresh()
 hip.lib().vp9hip_lf_frame_init(32, 0, None, None, 0, 0, None, None, None, ctypes.byref(th))
 pk = hip.Packer()
 L = pk.pack(P, blocks, eob)
-n_lds, row_pos, sb_rows = L["n_islands_lds"], L["island_row_pos"], L["sb_rows"]
+n_lds, row_pos, sb_rows, sb_cols = L["n_islands_lds"], L["island_row_pos"], L["sb_rows"], L["sb_cols"]
 isl, woff = L["intra_islands"], L["intra_island_wave_off"]
 print(f"{len(isl)} islands ({n_lds} in LDS), {len(L['intra_island_tasks'])} island tasks, {L['n_waves']} waves deep; row_pos {row_pos.tolist()}")
 dec = hip.Decoder(0)
@@ -84,6 +84,12 @@ print("filter rows (luma): row: start, first superblock ready, end (us after the
 for r in range(sb_rows):
     i = np.flatnonzero(rr == 3 * r)[0]
     print(f"  row {r:2d}: {us(R[i, 0]):7.1f} {us(R[i, 1]):7.1f} {us(R[i, 7]):7.1f}")
-print(f"launch span: {us(st[:, [6, 7]].max()):.1f} us")
+print("filter rows (luma), the filtering wave's time per superblock step, us: vertical pass | wait at the barrier behind it | horizontal pass | "
+      "wait at the barrier behind it | (wave 1's work beside the horizontal pass: gate, next interior from memory into LDS, controls)")
+for r in range(sb_rows):
+    i = np.flatnonzero(rr == 3 * r)[0]
+    a = R[i, 2:7] / 100.0 / sb_cols
+    print(f"  row {r:2d}: {a[0]:5.2f} | {a[1]:5.2f} | {a[2]:5.2f} | {a[3]:5.2f} | ({a[4]:5.2f})   sum {a[:4].sum():5.2f}")
+print(f"launch span: {max(us(S[:, 6]).max(), us(R[:, 7]).max()):.1f} us")
 dec.close()
 pk.close()
