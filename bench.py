@@ -590,6 +590,41 @@ def main():
             for _ in range(2 - barriers):
                 barrier()
 
+    # ---- extra leg (N = 1): the hot path on the north star's other geometries, same procedure as `value` ----------
+    other_geometries = None
+    if world == 1 and not args.no_stream and (W, H, bd) == (2560, 1440, 8):
+        other_geometries = {}
+        for key, (w2, h2, b2) in (("1080p_8bit", (1920, 1080, 8)), ("1440p_10bit", (2560, 1440, 10))):
+            try:
+                refs2, frames2 = make_frames(hip, w2, h2, b2, 0, 2)
+                P2 = frame_params(hip, w2, h2, b2)
+                d2 = hip.Decoder(gpu)
+                for k in range(3):
+                    d2.upload(k, refs2[k], w2, h2, b2)
+                d2.alloc_slot(3, w2, h2, b2)
+                d2.begin_frame(P2, frames2[0][0], frames2[0][2], frames2[0][1])
+                d2.set_timing(False)
+                for _ in range(10):
+                    d2.run(ALL, (0, 1, 2), 3, thresh=th)
+                d2.sync()
+                n2, t2 = 0, time.perf_counter()
+                while n2 < 200 or time.perf_counter() - t2 < 0.2:
+                    d2.run(ALL, (0, 1, 2), 3, thresh=th)
+                    n2 += 1
+                d2.sync()
+                t2 = time.perf_counter() - t2
+                import refframe as _rf
+                rf2 = _rf.RefFrame(_rf.load_ref(), frames2[0][0], w2, h2, b2, refs2, [(w2, h2)] * 3, frames2[0][1], frames2[0][2], tiles=2)
+                rf2.run()
+                dims2, _ = _rf.plane_dims(w2, h2)
+                got2 = [np.zeros((dd[1], dd[0]), np.uint16 if b2 > 8 else np.uint8) for dd in dims2]
+                d2.download(3, got2, w2, h2, b2)
+                other_geometries[key] = {"frames_per_s": round(n2 / t2, 1), "steps": n2,
+                                         "md5_match": _rf.frame_md5(got2, w2, h2) == _rf.frame_md5(rf2.planes(), w2, h2)}
+                d2.close()
+            except Exception as e:  # noqa: BLE001
+                other_geometries[key] = {"error": str(e)[:300]}
+
     # ---- extra leg (N > 1): the north star's batch — one real stream per GPU through the stand-alone decoder ------
     streams_per_gpu = None
     ivf_big = os.path.join(ROOT, "tests", "streams_big", "S-1440.ivf")
@@ -671,6 +706,7 @@ def main():
             "stream": stream, **extra_streams, "multi_stream": multi,
             # several decoders in flight on one GPU must never make a filter row give up (tests/test_gpu_multi_decoder.py)
             "multi_stream_ok": (None if multi is None else "error" not in multi),
+            "hot_path_other_geometries": other_geometries,
             "stream_per_gpu": streams_per_gpu, "placement": placement,
         }
         print(json.dumps(out))
