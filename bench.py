@@ -662,7 +662,7 @@ def main():
             # the launches of a frame as the product runs it: convolve, idct_add, walk_lf (island walk + loop filter)
             dom = max((k for k in kernels if k in ("convolve", "idct_add", "walk_lf")), key=lambda k: kernels[k]["ms_per_frame"])
             traffic, note = None, "not measured"
-            if not args.no_pmc and (W, H, bd) == (2560, 1440, 8):
+            if not args.no_pmc and world == 1 and (W, H, bd) == (2560, 1440, 8):  # (N > 1: the committed passes; no profiler beside other ranks)
                 key = {"convolve": "inter_reg_kernel", "idct_add": "idct_add_all_kernel", "walk_lf": "walk_lf_kernel"}[dom]
                 try:
                     traffic, note = measure_traffic(key)
