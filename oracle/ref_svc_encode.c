@@ -50,12 +50,13 @@ static int same_image(const vpx_image_t *a, const vpx_image_t *b) {
 
 int main(int argc, char **argv) {
   if (argc < 8) {
-    fprintf(stderr, "usage: ref_svc_encode in.yuv width height frames out.ivf layers intra_only_at [kbps] [speed]\n");
+    fprintf(stderr, "usage: ref_svc_encode in.yuv width height frames out.ivf layers intra_only_at [kbps] [speed] [bit depth 8|10|12]\n");
     return 2;
   }
   const int w = atoi(argv[2]), h = atoi(argv[3]), frames = atoi(argv[4]), layers = atoi(argv[6]), intra_at = atoi(argv[7]);
   const int kbps = argc > 8 ? atoi(argv[8]) : 1200, speed = argc > 9 ? atoi(argv[9]) : 6;
-  if (w <= 0 || h <= 0 || frames <= 0 || layers < 1 || layers > 3) return 2;
+  const int depth = argc > 10 ? atoi(argv[10]) : 8; /* > 8: profile 2, 16-bit little-endian source samples */
+  if (w <= 0 || h <= 0 || frames <= 0 || layers < 1 || layers > 3 || (depth != 8 && depth != 10 && depth != 12)) return 2;
   FILE *in = fopen(argv[1], "rb"), *out = fopen(argv[5], "wb");
   if (!in || !out) return 2;
 
@@ -63,6 +64,11 @@ int main(int argc, char **argv) {
   if (vpx_codec_enc_config_default(vpx_codec_vp9_cx(), &cfg, 0)) die("config", NULL);
   cfg.g_w = w;
   cfg.g_h = h;
+  if (depth > 8) {
+    cfg.g_profile = 2;
+    cfg.g_bit_depth = depth == 10 ? VPX_BITS_10 : VPX_BITS_12;
+    cfg.g_input_bit_depth = (unsigned)depth;
+  }
   cfg.g_timebase.num = 1;
   cfg.g_timebase.den = 30;
   cfg.g_pass = VPX_RC_ONE_PASS;
@@ -97,7 +103,7 @@ int main(int argc, char **argv) {
     cfg.ts_target_bitrate[0] = kbps;
   }
   vpx_codec_ctx_t enc, dec;
-  if (vpx_codec_enc_init(&enc, vpx_codec_vp9_cx(), &cfg, 0)) die("encoder init", &enc);
+  if (vpx_codec_enc_init(&enc, vpx_codec_vp9_cx(), &cfg, depth > 8 ? VPX_CODEC_USE_HIGHBITDEPTH : 0)) die("encoder init", &enc);
   if (vpx_codec_dec_init(&dec, vpx_codec_vp9_dx(), NULL, 0)) die("decoder init", &dec);
   vpx_svc_extra_cfg_t sp;
   memset(&sp, 0, sizeof(sp));
@@ -129,7 +135,9 @@ int main(int argc, char **argv) {
   fwrite(hdr, 1, 32, out);
 
   vpx_image_t raw;
-  if (!vpx_img_alloc(&raw, VPX_IMG_FMT_I420, w, h, 32)) return 3;
+  if (!vpx_img_alloc(&raw, depth > 8 ? VPX_IMG_FMT_I42016 : VPX_IMG_FMT_I420, w, h, 32)) return 3;
+  raw.bit_depth = (unsigned)depth;
+  const size_t bps = depth > 8 ? 2 : 1;
   int written = 0, intra_only_seen = 0;
   for (int i = 0; i <= frames; ++i) { /* one more call to flush */
     vpx_image_t *img = NULL;
@@ -137,7 +145,7 @@ int main(int argc, char **argv) {
       for (int p = 0; p < 3; ++p) {
         const int pw = p ? (w + 1) / 2 : w, ph = p ? (h + 1) / 2 : h;
         for (int y = 0; y < ph; ++y)
-          if (fread(raw.planes[p] + (size_t)y * raw.stride[p], 1, (size_t)pw, in) != (size_t)pw) die("short read of the source", NULL);
+          if (fread(raw.planes[p] + (size_t)y * raw.stride[p], bps, (size_t)pw, in) != (size_t)pw) die("short read of the source", NULL);
       }
       img = &raw;
       if (i == intra_at && layers > 1) {

@@ -79,10 +79,12 @@ STREAMS = {
 # Streams the command-line encoder cannot make (oracle/ref_svc_encode.c drives the reference's encoder API): spatial
 # layers — every superframe holds a half-size (quarter-size) frame and the frames predicted from it through scale
 # factors, so a frame's references have ANOTHER size (vp9_decodeframe.c:1781, 3232-3237) — and an intra-only frame in
-# mid-stream (:3182-3213).  name: (width, height, frames, seed, dx, dy, patch_prob, layers, intra_only_at, kbps, speed)
+# mid-stream (:3182-3213).  name: (width, height, frames, seed, dx, dy, patch_prob, layers, intra_only_at, kbps, speed[, bits])
+# s352_svc2_10: the same in profile 2 — scaled prediction with 16-bit samples at stream level
 SVC_STREAMS = {
     "s352_svc2": (352, 288, 8, 35202, 3, 2, 0.3, 2, 4, 700, 6),
     "s704_svc3": (704, 576, 6, 70403, 4, -2, 0.3, 3, 3, 1800, 7),
+    "s352_svc2_10": (352, 288, 6, 35210, -3, 2, 0.3, 2, 3, 900, 6, 10),
 }
 
 
@@ -152,14 +154,15 @@ def make(name):
 
 
 def make_svc(name):
-    w, h, n, seed, dx, dy, patch, layers, intra_at, kbps, speed = SVC_STREAMS[name]
+    w, h, n, seed, dx, dy, patch, layers, intra_at, kbps, speed = SVC_STREAMS[name][:11]
+    bits = SVC_STREAMS[name][11] if len(SVC_STREAMS[name]) > 11 else 8
     ivf = os.path.join(HERE, name + ".ivf")
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "src.yuv")
-        source(yuv, w, h, n, seed, dx, dy, 8, "420", patch, 0)
+        source(yuv, w, h, n, seed, dx, dy, bits, "420", patch, 0)
         # (the driver decodes every superframe with the stream oracle and compares the reference buffers with the
         # encoder's own: its `--test-decode=fatal`)
-        out = run([os.path.join(VPX, "ref_svc_encode"), yuv, str(w), str(h), str(n), ivf, str(layers), str(intra_at), str(kbps), str(speed)])
+        out = run([os.path.join(VPX, "ref_svc_encode"), yuv, str(w), str(h), str(n), ivf, str(layers), str(intra_at), str(kbps), str(speed), str(bits)])
         if "decoded identically" not in out:
             sys.exit(f"{name}: {out[-400:]}")
     lines = md5_list(os.path.join(VPX, "vpxdec_c"), ivf)
