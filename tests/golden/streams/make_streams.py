@@ -73,6 +73,15 @@ STREAMS = {
     # handle uint16 frames) and the north star's other size at 8 bits
     "S-1440-10": (2560, 1440, 30, 14410, 5, 3, 10, "420", 0.1, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=3", "--cq-level=26", "--tile-columns=3", "--lag-in-frames=0", "--passes=1"], True),
     "S-1080-8": (1920, 1080, 60, 10808, 6, -3, 8, "420", 0.1, 0, ["--cpu-used=2", "--cq-level=26", "--tile-columns=2", "--lag-in-frames=0", "--passes=1"], True),
+    # the encoder's dynamic resize (one-pass CBR far under the content's rate): NON-key frames of another size in
+    # mid-stream — 704x576, from frame 60 on 528x432, from frame 90 on 352x288 — predicted from the larger frames
+    # through scale factors 4/3, 2 and 3/2 (vp9_decodeframe.c:1781 setup_frame_size_with_refs, :3232 scale factors; the
+    # 64-phase scaled convolve with steps other than 32, vpx_convolve.c:22-535).  (The encoder does not resize frames
+    # under 426x240, vp9_ratectrl.c, hence the size.)
+    "S-704-resize": (704, 576, 120, 777, 5, 3, 8, "420", 0.9, 8,
+                     ["--rt", "--cpu-used=7", "--end-usage=cbr", "--target-bitrate=80", "--resize-allowed=1", "--lag-in-frames=0", "--passes=1",
+                      "--min-q=2", "--max-q=52", "--buf-sz=1000", "--buf-initial-sz=500", "--buf-optimal-sz=600", "--undershoot-pct=50",
+                      "--overshoot-pct=50", "--drop-frame=0"], True),
 }
 
 

@@ -32,7 +32,7 @@ def test_front_end_same_lists_for_every_thread_count(hip):
     assert len(one) == len(two) and all((a == b).all() for a, b in zip(one, two))
 
 
-@pytest.mark.parametrize("name", ["S-1440", "S-2176", "S-1080-10", "S-1440-10", "S-1080-8"])
+@pytest.mark.parametrize("name", ["S-1440", "S-2176", "S-1080-10", "S-1440-10", "S-1080-8", "S-704-resize"])
 def test_front_end_on_baseline_sized_streams(hip, name):
     path = os.path.join(BIG, name + ".ivf")
     if not os.path.exists(path):

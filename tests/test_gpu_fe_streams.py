@@ -43,7 +43,7 @@ def test_standalone_decoder_md5(name):
     check(SMALL, name, "--wide-slots")  # int32 slots throughout, the reference's width
 
 
-@pytest.mark.parametrize("name", ["S-1440", "S-1440-q44", "S-2160", "S-2176", "S-1080-10", "S-1440-10", "S-1080-8"])
+@pytest.mark.parametrize("name", ["S-1440", "S-1440-q44", "S-2160", "S-2176", "S-1080-10", "S-1440-10", "S-1080-8", "S-704-resize"])
 def test_standalone_decoder_md5_baseline_sized(name):
     if not os.path.exists(os.path.join(BIG, name + ".ivf")):
         pytest.skip("tests/streams_big not generated (make_streams.py --big)")

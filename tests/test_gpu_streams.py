@@ -79,7 +79,7 @@ def test_stream_md5_unchanged_reference_driver():
     check(HIP_A, SMALL, "s704_10")
 
 
-@pytest.mark.parametrize("name", ["S-1440", "S-1440-q44", "S-2160", "S-2176", "S-1080-10", "S-1440-10", "S-1080-8"])
+@pytest.mark.parametrize("name", ["S-1440", "S-1440-q44", "S-2160", "S-2176", "S-1080-10", "S-1440-10", "S-1080-8", "S-704-resize"])
 def test_baseline_sized_stream_md5(name):
     if not os.path.exists(os.path.join(BIG, name + ".ivf")):
         pytest.skip(f"tests/streams_big/{name}.ivf not generated (make_streams.py --big)")
