@@ -45,6 +45,12 @@ STREAMS = {
     "s704_10": (704, 576, 6, 710, 6, 2, 10, "420", 0.4, 0, ["--profile=2", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=2", "--cq-level=30", "--tile-columns=1", "--lag-in-frames=0", "--passes=1"], False),
     # 4:4:4 (profile 1): chroma planes as large as luma, loop-filtered with the luma masks (LF_PATH_444)
     "s352_444": (352, 288, 6, 444, 3, 2, 8, "444", 0.4, 0, ["--profile=1", "--cpu-used=2", "--cq-level=30", "--lag-in-frames=0", "--passes=1"], False),
+    # frames smaller than a block: 16x16, and 6x10 (chroma planes 3 samples wide: narrower than the dword the register
+    # convolve replicates edges from — every task goes through the generic kernel)
+    "s16x16": (16, 16, 5, 1616, 1, 1, 8, "420", 0.0, 0, ["--cpu-used=2", "--cq-level=20", "--lag-in-frames=0", "--passes=1"], False),
+    "s6x10": (6, 10, 5, 610, 1, 0, 8, "420", 0.0, 0, ["--cpu-used=2", "--cq-level=20", "--lag-in-frames=0", "--passes=1"], False),
+    # profile 3: 4:4:4 with 16-bit samples (the chroma planes on the luma path of the loop filter, full-size chroma convolve)
+    "s352_444_10": (352, 288, 4, 4410, -2, 3, 10, "444", 0.4, 0, ["--profile=3", "--bit-depth=10", "--input-bit-depth=10", "--cpu-used=2", "--cq-level=28", "--lag-in-frames=0", "--passes=1"], False),
     # syntax the streams above do not reach (all 352x288, a few frames):
     # segmentation: variance AQ (per-segment quantiser, segment map coded in every frame)
     "s352_aq1": (352, 288, 6, 3521, 3, 2, 8, "420", 0.4, 0, ["--cpu-used=2", "--cq-level=30", "--aq-mode=1", "--lag-in-frames=0", "--passes=1"], False),

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(REFDEC), reason="oracle/_ref/
 
 
 @pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444", "s352_aq1", "s352_aq3", "s352_er", "s352_fp", "s352_ll",
-                                  "s352_12", "s352_tr", "s352_svc2", "s704_svc3", "s352_svc2_10"])
+                                  "s352_12", "s352_tr", "s352_svc2", "s704_svc3", "s352_svc2_10", "s352_444_10", "s16x16", "s6x10"])
 def test_front_end_parses_what_the_reference_parses(hip, name):
     path = os.path.join(SMALL, name + ".ivf")
     mine = fe_compare.parse_stream(hip, path)

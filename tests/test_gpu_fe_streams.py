@@ -35,7 +35,7 @@ def check(d, name, *opts):
 
 
 @pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444", "s352_aq1", "s352_aq3", "s352_er", "s352_fp", "s352_ll",
-                                  "s352_12", "s352_tr", "s352_svc2", "s704_svc3", "s352_svc2_10"])
+                                  "s352_12", "s352_tr", "s352_svc2", "s704_svc3", "s352_svc2_10", "s352_444_10", "s16x16", "s6x10"])
 def test_standalone_decoder_md5(name):
     assert os.path.exists(DEC), "cuda-vp9_amd/vp9hip_dec not built (make -C cuda-vp9_amd)"
     check(SMALL, name)  # (int16 coefficient slots wherever a frame's coefficients fit: the default)

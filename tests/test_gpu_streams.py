@@ -56,13 +56,13 @@ def check(decoder, directory, name):
 
 
 @pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444", "s352_aq1", "s352_aq3", "s352_er", "s352_fp", "s352_ll", "s352_12",
-                                  "s352_tr", "s352_svc2", "s704_svc3", "s352_svc2_10"])
+                                  "s352_tr", "s352_svc2", "s704_svc3", "s352_svc2_10", "s352_444_10", "s16x16", "s6x10"])
 def test_stream_md5_patched_driver(name):
     check(HIP, SMALL, name)
 
 
 @pytest.mark.parametrize("name", ["s704_8", "s350_8", "s352_arf", "s704_10", "s352_444", "s352_aq1", "s352_aq3", "s352_er", "s352_fp", "s352_ll", "s352_12",
-                                  "s352_tr", "s352_svc2", "s704_svc3", "s352_svc2_10"])
+                                  "s352_tr", "s352_svc2", "s704_svc3", "s352_svc2_10", "s352_444_10", "s16x16", "s6x10"])
 def test_stream_md5_tile_parallel_entropy_stage(name):
     # every stream goes through the tile-column threads (one column: one thread) with compact coefficient slots
     check(HIP_MT, SMALL, name)
