@@ -18,6 +18,10 @@ __device__ __forceinline__ int clip_pix(int v, int maxv) {
 
 constexpr int TX_LDS_INTS = (256 / 32) * 32 * 33;  // the 32x32 class needs the most: 8 blocks x 32 rows x 33 dwords
 
+// A block's N lanes lie inside one wavefront (N <= 32) and its LDS tile is touched by them only; a wave's LDS
+// operations execute in issue order: the stages need the compiler pinned and lgkmcnt drained, not a workgroup barrier.
+__device__ __forceinline__ void tile_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local"); }
+
 template <int N, typename Pix, bool HBD>
 __device__ __forceinline__ void idct_add_body(int *lds, int wg, const vp9hip_txb *__restrict__ blocks, int n_blocks,
                                               const txfm::Coefs &coeffs, const FrameDev &f) {
@@ -46,7 +50,7 @@ __device__ __forceinline__ void idct_add_body(int *lds, int wg, const vp9hip_txb
 #pragma unroll
     for (int i = 0; i < N; ++i) tile[i * PITCH + t] = i < rd ? src[i * N + t] : 0;
   }
-  __syncthreads();
+  tile_sync();
   if (active && !dc_path && !wht_dc) {
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = tile[t * PITCH + k];
@@ -60,8 +64,7 @@ __device__ __forceinline__ void idct_add_body(int *lds, int wg, const vp9hip_txb
 #pragma unroll
     for (int k = 0; k < N; ++k) tile[t * PITCH + k] = v[k];
   }
-  __syncthreads();
-  if (!active) return;
+  tile_sync();
 
   constexpr int shift = N == 4 ? 4 : (N == 8 ? 5 : 6);
   if (dc_path) {
@@ -93,22 +96,55 @@ __device__ __forceinline__ void idct_add_body(int *lds, int wg, const vp9hip_txb
     }
   }
 
+  // ---- destination.  The column pass left lane t with COLUMN t of the residual; the frame is updated by ROWS: lane t
+  // takes row t through LDS once more and adds it to N consecutive samples — one load and one store of N samples per
+  // lane instead of N loads and N stores of one sample each (for the 4x4 blocks, two thirds of a frame's blocks, eight
+  // single-byte memory instructions per lane became two dword ones).
+  const bool uniform = dc_path;  // every sample of the block gets the same value: nothing to transpose
+  if (active && !uniform) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) tile[k * PITCH + t] = v[k];
+  }
+  tile_sync();
+  if (!active) return;
   const int pl = blk.plane;
-  Pix *dst = (Pix *)f.plane[pl];
   const int stride = f.stride[pl];
   const int maxv = (1 << f.bit_depth) - 1;
-  const int x = blk.x + t;
-  if (x >= f.awidth[pl]) return;
   const int rows = min(N, f.aheight[pl] - (int)blk.y);
-  Pix *p = dst + (size_t)blk.y * stride + x;
-  // all destination loads are issued before the first store (the compiler cannot prove that
-  // row k+1 does not alias row k and would otherwise serialise N load->store round trips)
-  int d[N];
+  const int cols = min(N, f.awidth[pl] - (int)blk.x);  // a multiple of 4 (block positions and awidth are)
+  if (t >= rows || cols <= 0) return;
+  int r[N];
 #pragma unroll
-  for (int k = 0; k < N; ++k) d[k] = (k < rows) ? (int)p[(size_t)k * stride] : 0;
+  for (int j = 0; j < N; ++j) r[j] = uniform ? v[0] : tile[t * PITCH + j];
+  Pix *p = (Pix *)f.plane[pl] + (size_t)(blk.y + t) * stride + blk.x;
+  constexpr int SPD = 4 / (int)sizeof(Pix);  // samples per dword
+  constexpr int ND = N / SPD;                // dwords per row
+  unsigned dw[ND];
+  const int vd = cols / SPD;                 // valid dwords of this row (cols is a multiple of 4)
+  if (vd == ND) {
+    __builtin_memcpy(dw, __builtin_assume_aligned(p, 4), ND * 4);
+  } else {
 #pragma unroll
-  for (int k = 0; k < N; ++k)
-    if (k < rows) p[(size_t)k * stride] = (Pix)clip_pix<Pix>(txfm::add32(d[k], v[k]), maxv);
+    for (int q = 0; q < ND; ++q) dw[q] = q < vd ? ((const unsigned *)p)[q] : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < ND; ++q) {
+    unsigned o = 0;
+#pragma unroll
+    for (int e = 0; e < SPD; ++e) {
+      const int sh = e * 8 * (int)sizeof(Pix);
+      const int smp = (int)((dw[q] >> sh) & (sizeof(Pix) == 1 ? 0xffu : 0xffffu));
+      o |= (unsigned)clip_pix<Pix>(txfm::add32(smp, r[q * SPD + e]), maxv) << sh;
+    }
+    dw[q] = o;
+  }
+  if (vd == ND) {
+    __builtin_memcpy(__builtin_assume_aligned(p, 4), dw, ND * 4);
+  } else {
+#pragma unroll
+    for (int q = 0; q < ND; ++q)
+      if (q < vd) ((unsigned *)p)[q] = dw[q];
+  }
 }
 
 // All four transform sizes in one launch: workgroups [wg_start[k], wg_start[k+1]) serve size class k
