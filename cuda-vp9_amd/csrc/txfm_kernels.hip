@@ -46,14 +46,23 @@ __device__ __forceinline__ void idct_add_body(int *lds, int wg, const vp9hip_txb
 
   int v[N];
   if (active && !dc_path && !wht_dc) {
-    const int rd = txfm::coeff_rows(eob, lossless ? 0 : tx_type, N);  // rows past rd are zero and, in a compact slot, absent
+    // Lane t reads ROW t of the coefficients straight into its registers — N consecutive coefficients, 16 bytes per
+    // load (a slot starts at a multiple of N coefficients) — instead of N single loads that went through LDS to be
+    // turned from columns into rows.  Rows past rd are zero and, in a compact slot, absent.
+    const int rd = txfm::coeff_rows(eob, lossless ? 0 : tx_type, N);
+    if (t < rd) {
+      if (coeffs.c16) {
+        short c[N];
+        __builtin_memcpy(c, __builtin_assume_aligned((const short *)coeffs.p + blk.coeff_off + (unsigned)(t * N), 4), N * 2);
 #pragma unroll
-    for (int i = 0; i < N; ++i) tile[i * PITCH + t] = i < rd ? src[i * N + t] : 0;
-  }
-  tile_sync();
-  if (active && !dc_path && !wht_dc) {
+        for (int k = 0; k < N; ++k) v[k] = c[k];
+      } else {
+        __builtin_memcpy(v, __builtin_assume_aligned((const int *)coeffs.p + blk.coeff_off + (unsigned)(t * N), 4), N * 4);
+      }
+    } else {
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = tile[t * PITCH + k];
+      for (int k = 0; k < N; ++k) v[k] = 0;
+    }
     if (lossless) {
       if constexpr (N == 4) txfm::iwht4(v, true);
     } else if (N < 32 && (tx_type & 2)) {  // DCT_ADST / ADST_ADST: adst on rows

@@ -103,7 +103,7 @@ typedef struct vp9hip_frame {
  * (vp9/common/vp9_idct.c:119-204, highbd :308-396).
  * ---------------------------------------------------------------------------------------- */
 typedef struct vp9hip_txb {
-  uint32_t coeff_off; /* index of this block's first coefficient in the coefficient buffer */
+  uint32_t coeff_off; /* index of this block's first coefficient in the coefficient buffer (a multiple of 4: slots hold whole rows) */
   uint16_t x, y;      /* top-left pixel of the block inside its plane */
   uint8_t plane;      /* 0..2 */
   uint8_t tx_size;    /* 0: 4x4, 1: 8x8, 2: 16x16, 3: 32x32 */
