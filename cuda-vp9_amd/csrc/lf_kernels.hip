@@ -127,7 +127,7 @@ __device__ __forceinline__ void filter_window(int *w, int q, int kind, unsigned 
 // ---- per-mask-bit filter controls (lane = mask bit) --------------------------------------------
 template <int N>
 __device__ __forceinline__ void lf_controls(unsigned *ctl, const vp9hip_lfm &m, int pl, int mi_row, int rows_mi,
-                                            int mi_rows, const LfThreshDev &th) {
+                                            int mi_rows, const unsigned *thr_tab /* LDS: per level, mblim | lim << 8 | hev_thr << 16 */) {
   const int lane = threadIdx.x & 63;
   constexpr int ncol = N / 8;
   constexpr int nbits = ncol * ncol;
@@ -156,7 +156,10 @@ __device__ __forceinline__ void lf_controls(unsigned *ctl, const vp9hip_lfm &m, 
       if (c > 0) level_left = m.lfl_y[mr * 16 + (c - 1) * 2];
       if (mr > 0) level_up = m.lfl_y[(mr - 1) * 16 + c * 2];
     }
-    auto thr3 = [&](int lv) { return (unsigned)th.mblim[lv] | ((unsigned)th.lim[lv] << 8) | ((unsigned)th.hev_thr[lv] << 16); };
+    // (a table in LDS: indexed by a per-lane level, the thresholds in the kernel's arguments were three single-byte
+    // loads from memory behind the load of the level — two dependent round trips in wave 1's work beside the
+    // horizontal pass, which frames of real streams wait for)
+    auto thr3 = [&](int lv) { return thr_tab[lv & 63]; };
     const int bit = lane;
     // vertical pass
     {
@@ -376,7 +379,7 @@ __device__ __forceinline__ void st_granule(lf_granule *p, unsigned data, unsigne
 template <typename Pix, int N, int SH>
 __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const vp9hip_lfm *__restrict__ lfms,
                                              int sb_cols, int sr, int pl, const LfThreshDev &th, const FrameDev &f,
-                                             int mi_rows, int *err, volatile unsigned *flags,
+                                             int mi_rows, int *err, volatile unsigned *flags, const unsigned *thr_tab,
                                              const int *gate_done, const int *gate_expected, int sb_rows,
                                              lf_granule *hand_base, unsigned gen, const int *ticket) {
   constexpr int TP = TileCfg<Pix>::TP;
@@ -427,7 +430,7 @@ __device__ __forceinline__ void lf_row2_body(Pix *tiles, unsigned *ctls, const v
       const int r = i / DPR, d = i - r * DPR;
       if (i < n * DPR) t32[(8 + r) * TPD + 8 / PPD + d] = reg[k];
     }
-    lf_controls<N>(ctls + (sc & 1) * 256, lfms[sr * sb_cols + sc], pl, mi_row, rows_mi, mi_rows, th);
+    lf_controls<N>(ctls + (sc & 1) * 256, lfms[sr * sb_cols + sc], pl, mi_row, rows_mi, mi_rows, thr_tab);
   };
   // Running beside the intra island walk (vp9hip_intra_islands_lf): superblock (sr, c) may be loaded
   // and filtered once every island touching superblocks (sr..sr+1, c-1..c+1) is done — an unfinished
@@ -659,6 +662,7 @@ struct LfRowLds {
   __attribute__((aligned(16))) Pix tiles[2 * 72 * TileCfg<Pix>::TP];
   unsigned ctls[2 * 256];
   unsigned flags[2];
+  unsigned thr[64];  // per filter level: mblim | lim << 8 | hev_thr << 16
 };
 
 template <typename Pix, int SH>
@@ -666,11 +670,13 @@ __device__ __forceinline__ void lf_row_entry(LfRowLds<Pix> &L, const vp9hip_lfm 
                                              const LfThreshDev &th, const FrameDev &f, int mi_rows, int *err,
                                              const int *gate_done, const int *gate_expected, lf_granule *hand, unsigned gen,
                                              int sr, int pl, const int *ticket) {
+  if (threadIdx.x < 64) L.thr[threadIdx.x] = (unsigned)th.mblim[threadIdx.x] | ((unsigned)th.lim[threadIdx.x] << 8) | ((unsigned)th.hev_thr[threadIdx.x] << 16);
+  __syncthreads();
   if (pl == 0 || f.awidth[pl] == f.awidth[0])
-    lf_row2_body<Pix, 64, SH>(L.tiles, L.ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, err, L.flags, gate_done, gate_expected,
+    lf_row2_body<Pix, 64, SH>(L.tiles, L.ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, err, L.flags, L.thr, gate_done, gate_expected,
                               sb_rows, hand, gen, ticket);
   else
-    lf_row2_body<Pix, 32, SH>(L.tiles, L.ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, err, L.flags, gate_done, gate_expected,
+    lf_row2_body<Pix, 32, SH>(L.tiles, L.ctls, lfms, sb_cols, sr, pl, th, f, mi_rows, err, L.flags, L.thr, gate_done, gate_expected,
                               sb_rows, hand, gen, ticket);
 }
 
