@@ -185,6 +185,35 @@ __device__ __forceinline__ void row_pass(int *tile, int t, int tx_type, bool los
   for (int k = 0; k < N; ++k) tile[t * PITCH + k] = v[k];
 }
 
+// The row pass with the row taken straight from the coefficient buffer (N consecutive coefficients, 16 bytes per load;
+// rows >= rd are zero and, in a compact slot, absent) instead of through the LDS tile: txfm_kernels.hip, round 3.
+template <int N, bool HBD, int PITCH = TPITCH>
+__device__ __forceinline__ void row_pass_from(int *tile, int t, int tx_type, bool lossless, const txfm::Coefs &coeffs, unsigned off, int rd) {
+  int v[N];
+  if (t < rd) {
+    if (coeffs.c16) {
+      short c[N];
+      __builtin_memcpy(c, __builtin_assume_aligned((const short *)coeffs.p + off + (unsigned)(t * N), 4), N * 2);
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = c[k];
+    } else {
+      __builtin_memcpy(v, __builtin_assume_aligned((const int *)coeffs.p + off + (unsigned)(t * N), 4), N * 4);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = 0;
+  }
+  if (lossless) {
+    if constexpr (N == 4) txfm::iwht4(v, true);
+  } else if (N < 32 && (tx_type & 2)) {
+    if constexpr (N < 32) txfm::iadst1d<N, HBD>(v);
+  } else {
+    txfm::idct1d<N, HBD>(v);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) tile[t * PITCH + k] = v[k];
+}
+
 template <int N, bool HBD, int PITCH = TPITCH>
 __device__ __forceinline__ void col_pass(const int *tile, int t, int tx_type, bool lossless, int *v) {
   constexpr int shift = N == 4 ? 4 : (N == 8 ? 5 : 6);
@@ -511,9 +540,8 @@ __device__ __forceinline__ void island_residual_pass(IslandLds &S, int first, in
     short *dst = &S.tile[S.idx0[pl] + (int)tk.y * pitch + (int)tk.x + t];
     const bool full = active && kind == 0;
     if (full) {
-      const int rd = txfm::coeff_rows(tk.eob, lossless ? 0 : (tk.tx_type & 3), N);
-#pragma unroll
-      for (int i = 0; i < N; ++i) pt[i * PITCH + t] = i < rd ? src[i * N + t] : 0;
+      row_pass_from<N, HBD, PITCH>(pt, t, tt, N == 4 && lossless, coeffs, tk.coeff_off,
+                                   txfm::coeff_rows(tk.eob, lossless ? 0 : (tk.tx_type & 3), N));
     } else if (active) {
       if (kind == 3) {  // the slot holds the residual itself
         for (int k = 0; k < N; ++k) dst[k * pitch] = sat16(src[k * N + t]);
@@ -529,8 +557,6 @@ __device__ __forceinline__ void island_residual_pass(IslandLds &S, int first, in
         dst[pitch] = dst[2 * pitch] = dst[3 * pitch] = sat16(e);
       }
     }
-    slot_sync();
-    if (full) row_pass<N, HBD, PITCH>(pt, t, tt, N == 4 && lossless);
     slot_sync();
     if (full) {
       int v[N];
