@@ -257,8 +257,10 @@ __device__ __forceinline__ void block_residual(const vp9hip_intra_task &tk, int 
   }
 }
 
+__device__ __forceinline__ void slot_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local"); }
+
 template <int N, typename Pix, bool HBD>
-__device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t, const int *E, const int *tile,
+__device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t, const int *E, int *tile,
                                              bool coded, int dc_coeff, int dc_kind, const FrameDev &f) {
   if (t >= N) return;
   int p[N];
@@ -270,14 +272,35 @@ __device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t,
 #pragma unroll
     for (int k = 0; k < N; ++k) p[k] = clip_to(txfm::add32(p[k], v[k]), maxv);
   }
-  const int pl = tk.plane;
-  const int x = tk.x + t;
-  if (x >= f.awidth[pl]) return;
-  Pix *dst = (Pix *)f.plane[pl] + (size_t)tk.y * f.stride[pl] + x;
-  const int rows = min(N, f.aheight[pl] - (int)tk.y);
+  // The block goes to the frame by ROWS: lane t holds column t, the columns meet in the slot's LDS tile (free once the
+  // residual was taken from it) and lane t stores row t in one piece — N samples per store instead of N stores of one
+  // sample per lane (txfm_kernels.hip, round 3; a 32x32 block: 32 stores per lane became two).
 #pragma unroll
-  for (int k = 0; k < N; ++k)
-    if (k < rows) dst[(size_t)k * f.stride[pl]] = (Pix)p[k];
+  for (int k = 0; k < N; ++k) tile[k * TPITCH + t] = p[k];
+  slot_sync();
+  const int pl = tk.plane;
+  const int rows = min(N, f.aheight[pl] - (int)tk.y);
+  const int cols = min(N, f.awidth[pl] - (int)tk.x);  // a multiple of 4
+  if (t >= rows || cols <= 0) return;
+  Pix *dst = (Pix *)f.plane[pl] + (size_t)(tk.y + t) * f.stride[pl] + tk.x;
+  constexpr int SPD = 4 / (int)sizeof(Pix);  // samples per dword
+  constexpr int ND = N / SPD;
+  unsigned dw[ND];
+#pragma unroll
+  for (int q = 0; q < ND; ++q) {
+    unsigned o = 0;
+#pragma unroll
+    for (int e = 0; e < SPD; ++e) o |= (unsigned)tile[t * TPITCH + q * SPD + e] << (e * 8 * (int)sizeof(Pix));
+    dw[q] = o;
+  }
+  const int vd = cols / SPD;
+  if (vd == ND) {
+    __builtin_memcpy(__builtin_assume_aligned(dst, 4), dw, ND * 4);
+  } else {
+#pragma unroll
+    for (int q = 0; q < ND; ++q)
+      if (q < vd) ((unsigned *)dst)[q] = dw[q];
+  }
 }
 
 // Up to SLOTS (8) independent transform blocks, one per 32-lane slot.  `active` slots predict (and
@@ -286,7 +309,6 @@ __device__ __forceinline__ void finish_block(const vp9hip_intra_task &tk, int t,
 // slot only; a wave's LDS operations execute in issue order.  The stages of a chunk therefore need the
 // compiler pinned and lgkmcnt drained, not a workgroup barrier (which made the four waves of an island
 // wait for the slowest one, twice per chunk, and drained its global stores as well).
-__device__ __forceinline__ void slot_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local"); }
 
 template <typename Pix, bool HBD>
 __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 * TPITCH],
@@ -354,20 +376,20 @@ __device__ __forceinline__ void intra_chunk(int (*edge)[ESIZE], int (*tiles)[32 
       }
       if (dc_kind)
         dc_coeff = src[0];  // only the DC term is defined (and read) at eob <= 1
-      else if (t < bs) {
-        const int rd = identity ? bs : txfm::coeff_rows(tk.eob, lossless ? 0 : (tk.tx_type & 3), bs);
-        for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = i < rd ? src[i * bs + t] : 0;
+      else if (identity && t < bs) {
+        for (int i = 0; i < bs; ++i) tile[i * TPITCH + t] = src[i * bs + t];
       }
     }
   }
   slot_sync();
-  if (coded && !dc_kind && !identity && t < bs) {
+  if (coded && !dc_kind && !identity && t < bs) {  // (the rows of coefficients straight from memory into the row pass)
     const int tt = tk.tx_type & 3;
+    const int rd = txfm::coeff_rows(tk.eob, lossless ? 0 : tt, bs);
     switch (tk.tx_size) {
-      case 0: row_pass<4, HBD>(tile, t, tt, lossless); break;
-      case 1: row_pass<8, HBD>(tile, t, tt, false); break;
-      case 2: row_pass<16, HBD>(tile, t, tt, false); break;
-      default: row_pass<32, HBD>(tile, t, 0, false); break;
+      case 0: row_pass_from<4, HBD>(tile, t, tt, lossless, coeffs, tk.coeff_off, rd); break;
+      case 1: row_pass_from<8, HBD>(tile, t, tt, false, coeffs, tk.coeff_off, rd); break;
+      case 2: row_pass_from<16, HBD>(tile, t, tt, false, coeffs, tk.coeff_off, rd); break;
+      default: row_pass_from<32, HBD>(tile, t, 0, false, coeffs, tk.coeff_off, rd); break;
     }
   }
   slot_sync();
