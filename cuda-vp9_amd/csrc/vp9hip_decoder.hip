@@ -137,13 +137,15 @@ __global__ __launch_bounds__(256) void gather_upload_kernel(UpPlan pl) {
   for (unsigned i = done + threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
-static bool host_is_pinned(const void *p) {
+// the device's address of page-locked host memory (hipHostMalloc: the same address; registered memory: its mapping),
+// NULL for pageable memory
+static const char *host_device_address(const void *p) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
     (void)hipGetLastError();  // (a pageable pointer is reported as an error: clear it)
-    return false;
+    return NULL;
   }
-  return a.type == hipMemoryTypeHost;
+  return a.type == hipMemoryTypeHost ? (const char *)a.devicePointer : NULL;
 }
 
 static int up_flush(vp9hip_decoder *dec, UpPlan *pl, hipStream_t st) {
@@ -425,9 +427,9 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
   UpPlan up;
   up.n = 0;
   up.wgs = 0;
-  bool coef_pinned[3] = { false, false, false };
+  const char *coef_dev[3] = { NULL, NULL, NULL };  // the coefficient arrays as the device sees them (page-locked ones)
   if (dqcoeff && (flags & VP9HIP_BEGIN_HOST_PERSISTENT))
-    for (int p = 0; p < 3; ++p) coef_pinned[p] = dqcoeff[p] && host_is_pinned(dqcoeff[p]);
+    for (int p = 0; p < 3; ++p) coef_dev[p] = dqcoeff[p] ? host_device_address(dqcoeff[p]) : NULL;
   if (early) {
     if (layout->total < 0 || layout->total > (int64_t)UINT32_MAX)
       DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: bad coefficient total");
@@ -441,7 +443,8 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
       }
       if (g->count &&
           (rc = up_add(dec, &up, (char *)S->d_coeffs.p + esz * (size_t)(layout->plane_base[g->plane] + g->start),
-                       (const char *)dqcoeff[g->plane] + esz * (size_t)g->start, esz * (size_t)g->count, coef_pinned[g->plane], cs)))
+                       (coef_dev[g->plane] ? coef_dev[g->plane] : (const char *)dqcoeff[g->plane]) + esz * (size_t)g->start,
+                       esz * (size_t)g->count, coef_dev[g->plane] != NULL, cs)))
         return rc;
     }
     if ((rc = up_flush(dec, &up, cs))) return rc;  // (the coefficients travel while the lists are built)
@@ -488,7 +491,8 @@ extern "C" int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_f
         DEC_FAIL(dec, VP9HIP_EINVAL, "vp9hip_decoder_begin_frame: coefficient region %lld out of range", (long long)r);
       if (g->count &&
           (rc = up_add(dec, &up, (char *)S->d_coeffs.p + esz * (size_t)(layout->plane_base[g->plane] + g->start),
-                       (const char *)dqcoeff[g->plane] + esz * (size_t)g->start, esz * (size_t)g->count, coef_pinned[g->plane], cs)))
+                       (coef_dev[g->plane] ? coef_dev[g->plane] : (const char *)dqcoeff[g->plane]) + esz * (size_t)g->start,
+                       esz * (size_t)g->count, coef_dev[g->plane] != NULL, cs)))
         return rc;
     }
   } else if (dqcoeff)
