@@ -73,7 +73,9 @@ int vp9hip_decoder_begin_frame(vp9hip_decoder *dec, const vp9hip_frame_params *p
 
 /* Same, with flags.  VP9HIP_BEGIN_HOST_PERSISTENT: dqcoeff[] point into page-locked memory (e.g.
  * vp9hip_decoder_host_alloc) that stays untouched until the frame has been run and synchronised — the
- * coefficient copy is then asynchronous as well and the call returns as soon as the frame is packed. */
+ * coefficient copy is then asynchronous as well and the call returns as soon as the frame is packed; the device
+ * reads such arrays in place (one gather launch on the copy stream for all regions and lists of the frame instead of a
+ * copy call per region). */
 #define VP9HIP_BEGIN_HOST_PERSISTENT 1
 int vp9hip_decoder_begin_frame_ex(vp9hip_decoder *dec, const vp9hip_frame_params *params, const vp9hip_block *blocks,
                                   int n_blocks, const vp9hip_coeff_layout *layout, const int32_t *const dqcoeff[3], int flags);
